@@ -1,0 +1,166 @@
+/*
+ * wavenet_amd.h -- C ABI of libwavenet_amd.so: the MI355X (gfx950) implementation of the
+ * WaveNet dilated residual-block hot path of paultsw/wavenet-speech.
+ *
+ * The reference has no FFI layer (it is pure Python on stock PyTorch ops); the
+ * boundary it exposes for this path is the nn.Module surface
+ *     modules/conv_ops.py:8-79   CausalConv1d / NonCausalConv1d
+ *     modules/block.py:15-82     ResidualBlock(in,out,k,d,causal).forward(seq) -> (residual_out, skip_out)
+ *     modules/wavenet.py:98-100  the per-layer loop  out,skip = convolutions[l](out); skips_sum += bottlenecks[l](skip)
+ * Each entry point below names the reference code it replaces.  The Python host side
+ * (wavenet_speech_amd/) binds these with ctypes and re-creates that nn.Module surface on top.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, ints, a stream handle (hipStream_t passed as void*).  No torch types.
+ *  - the library never allocates or frees device memory and keeps no device state: every buffer
+ *    (activations, packed weights, saved tensors, workspaces) is owned by the caller.
+ *  - every function only enqueues work on `stream` and returns 0 or a negative wn_status code;
+ *    no exceptions cross the ABI.  wn_strerror() gives the text.
+ *  - re-entrant; one process per GPU for data parallelism.
+ *  - dtype: fp32 storage, fp32 arithmetic (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+ *
+ * Padded series layout (all activation tensors -- "series" of B utterances x C channels x L steps)
+ *    float buf[B][Cp][ld],  Cp = wn_round_up(C, 8),  ld = halo + wn_round_up(L,128) + halo
+ *    sample (b, c, t) lives at buf[(b*Cp + c)*ld + halo + t];   halo = wn_round_up(max |tap offset|, 4)
+ *    EVERYTHING outside the valid [C][L] window (pad rows, both halos, the tail up to the next
+ *    multiple of 128) MUST be zero on input and is kept zero on output.  This is what lets the
+ *    kernels read the dilated taps x[t-d] with unmasked, time-coalesced 16-byte loads.
+ *    wn_series_layout() computes (ld, halo, Cp) so host code never hard-codes the rule.
+ */
+#ifndef WAVENET_AMD_H
+#define WAVENET_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_VERSION 100 /* 0.1.0 */
+
+typedef void* wn_stream_t; /* hipStream_t */
+
+typedef enum wn_status {
+    WN_OK = 0,
+    WN_ERR_BAD_SHAPE = -1,   /* non-positive / inconsistent dimension, or layout (ld, halo) too small for the taps */
+    WN_ERR_UNSUPPORTED = -2, /* kernel_width > WN_MAX_TAPS or channel count > WN_MAX_CHANNELS */
+    WN_ERR_NULL = -3,        /* a required pointer is NULL */
+    WN_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed (see wn_last_hip_error) */
+    WN_ERR_WORKSPACE = -5    /* workspace smaller than wn_*_workspace_bytes() */
+} wn_status;
+
+#define WN_MAX_TAPS 4
+#define WN_MAX_CHANNELS 1024
+
+/* Shape of one residual block call.  Mirrors ResidualBlock.__init__ (modules/block.py:22-51)
+ * plus the batch geometry.  `skip_rows` is the row count of the skip projection: Co for the
+ * stand-alone block (conv1x1_skip), or out_dim when the host has folded the stack's bottleneck
+ * 1x1 into it (W = bottleneck.W @ conv1x1_skip.W, modules/wavenet.py:99-100). */
+typedef struct wn_block_shape {
+    int batch;        /* B */
+    int length;       /* L, valid time steps */
+    int in_channels;  /* Ci */
+    int out_channels; /* Co */
+    int skip_rows;    /* Ms */
+    int kernel_width; /* k  (1..WN_MAX_TAPS) */
+    int dilation;     /* d */
+    int causal;       /* 1: CausalConv1d taps (j-(k-1))*d ; 0: NonCausalConv1d taps j*d - autopad(k,d) */
+    int ld;           /* row pitch of every series buffer, floats */
+    int halo;         /* zero columns before t=0 (and after the 128-rounded tail) */
+} wn_block_shape;
+
+/* The ten parameter tensors of a ResidualBlock in PyTorch's native layouts
+ * (state_dict keys of modules/block.py:42-48).  Used for parameters and for their gradients. */
+typedef struct wn_block_params {
+    float* w_tanh;    /* conv_tanh.conv1d.weight     [Co][Ci][k] */
+    float* b_tanh;    /* conv_tanh.conv1d.bias       [Co]        */
+    float* w_sigmoid; /* conv_sigmoid.conv1d.weight  [Co][Ci][k] */
+    float* b_sigmoid; /* conv_sigmoid.conv1d.bias    [Co]        */
+    float* w_res;     /* conv1x1_residual.weight     [Co][Co](1) */
+    float* b_res;     /* conv1x1_residual.bias       [Co]        */
+    float* w_skip;    /* conv1x1_skip.weight         [Ms][Co](1)  (or the folded bottleneck*skip matrix) */
+    float* b_skip;    /* conv1x1_skip.bias           [Ms]        */
+    float* w_proj;    /* residual_proj.weight        [Co][Ci]    */
+    float* b_proj;    /* residual_proj.bias          [Co]        */
+} wn_block_params;
+
+int wn_version(void);
+const char* wn_strerror(int status);
+/* text of the last HIP error seen by this thread's calls (empty string if none) */
+const char* wn_last_hip_error(void);
+
+int wn_round_up(int x, int multiple);
+/* modules/conv_ops.py:104-116 autopad and the tap offsets of both conv flavours (off[j], j<k). */
+int wn_autopad(int kernel_width, int dilation);
+int wn_tap_offsets(int kernel_width, int dilation, int causal, int* off /* [k] */);
+/* Padded series layout for L steps and taps reaching at most max_abs_offset columns away. */
+int wn_series_layout(int length, int max_abs_offset, int* ld, int* halo);
+/* floats in one series buffer of `channels` channels: B * round_up(C,8) * ld */
+size_t wn_series_floats(int batch, int channels, int ld);
+
+/* ---- weights: repack PyTorch-layout parameters into MFMA-fragment order -------------------
+ * Once per optimizer step (weights are constant across the batch).  `packed` must hold
+ * wn_block_packed_bytes() bytes; it is consumed by wn_block_forward / wn_block_backward_data. */
+size_t wn_block_packed_bytes(const wn_block_shape* s);
+int wn_block_pack(const wn_block_shape* s, const wn_block_params* p, void* packed, wn_stream_t stream);
+
+/* ---- forward: replaces ResidualBlock.forward (modules/block.py:54-82) ----------------------
+ *   a = conv_tanh(x), g = conv_sigmoid(x); ta = tanh(a), sg = sigmoid(g); z = ta*sg
+ *   r    = W_res z + b_res + W_proj x + b_proj                       -> r_out (may be NULL: not needed)
+ *   skip = W_skip z + b_skip                                         -> skip  (skip_accumulate=0)
+ *   skip += W_skip z + b_skip   (the stack's running skips_sum)       -> skip  (skip_accumulate=1)
+ *   ta, sg, z are saved for the backward pass (each may be NULL for inference, all-or-none).
+ * x: [B][Ci8][ld]; r_out, ta, sg, z: [B][Co8][ld]; skip: [B][Ms8][ld]. */
+int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x,
+                     float* r_out, float* skip, int skip_accumulate,
+                     float* ta, float* sg, float* z, wn_stream_t stream);
+
+/* ---- backward (data): what autograd computes through modules/block.py:54-82 ----------------
+ *   dz = W_res^T dr + W_skip^T dskip ;  da = dz*sg*(1-ta^2) ;  dg = dz*ta*sg*(1-sg)     -> da, dg
+ *   dx[t] = W_proj^T dr[t] + sum_j (W_tanh_j^T da + W_sigmoid_j^T dg)[t - off_j]         -> dx (may be NULL)
+ * dr may be NULL (residual output unused, e.g. the last block of the stack).
+ * dr, da, dg: [B][Co8][ld]; dskip: [B][Ms8][ld]; dx: [B][Ci8][ld]. */
+int wn_block_backward_data(const wn_block_shape* s, const void* packed,
+                           const float* dr, const float* dskip, const float* ta, const float* sg,
+                           float* da, float* dg, float* dx, wn_stream_t stream);
+
+/* ---- backward (weights): time/batch-summed outer products -> gradients in PyTorch layouts ---
+ *   dW_tanh[:,:,j] = sum da[t] x[t+off_j]^T, dW_sigmoid likewise with dg, dW_res = sum dr z^T,
+ *   dW_proj = sum dr x^T, dW_skip = sum dskip z^T, biases = row sums.  Deterministic (split-K
+ *   partial slabs reduced in a fixed order).  Gradients are OVERWRITTEN, not accumulated.
+ *   dr may be NULL: then dW_res, db_res, dW_proj, db_proj are written as zeros. */
+size_t wn_block_wgrad_workspace_bytes(const wn_block_shape* s);
+int wn_block_backward_weights(const wn_block_shape* s, const float* x, const float* z,
+                              const float* da, const float* dg, const float* dr, const float* dskip,
+                              const wn_block_params* grads, void* workspace, size_t workspace_bytes,
+                              wn_stream_t stream);
+
+/* ---- stand-alone dilated conv: CausalConv1d / NonCausalConv1d (modules/conv_ops.py:8-79) ---
+ * and, with kernel_width=1, any 1x1 Conv1d.  y = sum_j W[:,:,j] x[t+off_j] + b. */
+typedef struct wn_conv_shape {
+    int batch, length, in_channels, out_channels, kernel_width, dilation, causal, ld, halo;
+} wn_conv_shape;
+size_t wn_conv_packed_bytes(const wn_conv_shape* s);
+int wn_conv_pack(const wn_conv_shape* s, const float* weight /*[Co][Ci][k]*/, const float* bias /*[Co] or NULL*/,
+                 void* packed, wn_stream_t stream);
+int wn_conv_forward(const wn_conv_shape* s, const void* packed, const float* x, float* y, wn_stream_t stream);
+int wn_conv_backward_data(const wn_conv_shape* s, const void* packed, const float* dy, float* dx, wn_stream_t stream);
+size_t wn_conv_wgrad_workspace_bytes(const wn_conv_shape* s);
+int wn_conv_backward_weights(const wn_conv_shape* s, const float* x, const float* dy,
+                             float* dweight, float* dbias /* may be NULL */,
+                             void* workspace, size_t workspace_bytes, wn_stream_t stream);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of every kernel on its launch stream ----
+ * Kernel classes: index into wn_prof_kernel_name().  wn_prof_collect() synchronises the recorded
+ * events and adds them to the per-class totals; wn_prof_get() reads them. */
+int wn_prof_enable(int on);
+int wn_prof_reset(void);
+int wn_prof_collect(void);
+int wn_prof_num_kernels(void);
+const char* wn_prof_kernel_name(int kernel_class);
+int wn_prof_get(int kernel_class, double* total_ms, long long* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_AMD_H */

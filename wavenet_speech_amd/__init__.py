@@ -1,0 +1,15 @@
+"""
+wavenet_speech_amd -- MI355X-native WaveNet dilated residual-block stack behind the nn.Module surface of
+paultsw/wavenet-speech (modules.wavenet.WaveNet, modules.raw_ctcnet.RawCTCNet, modules.block.ResidualBlock,
+modules.classifier.WaveNetClassifier, modules.conv_ops.*).
+
+    from wavenet_speech_amd.modules.wavenet import WaveNet      # instead of: from modules.wavenet import WaveNet
+
+All arithmetic of the hot path runs in hand-written HIP kernels (csrc/, gfx950) reached through the C ABI of
+libwavenet_amd.so (include/wavenet_amd.h).  No CPU fallback exists.
+"""
+from . import functional, modules, series  # noqa: F401
+from .modules import (CausalConv1d, NonCausalConv1d, RawCTCNet, ResidualBlock, WaveNet,  # noqa: F401
+                      WaveNetClassifier)
+
+__version__ = "0.1.0"

@@ -1,0 +1,311 @@
+"""
+Host side of the hot path: torch.autograd.Function wrappers that drive libwavenet_amd.so through its
+C ABI.  torch supplies device memory, the current HIP stream and autograd bookkeeping -- all arithmetic
+(dilated convs, gate, 1x1 products, every gradient) runs in the HIP kernels.
+
+There is no CPU path: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from .series import Lease, SeriesLayout, fresh_series, load_series, window
+
+PARAMS_PER_BLOCK = 10  # order = _lib.BlockParams fields
+
+
+class BlockSpec(object):
+    """Static description of one residual block (modules/block.py:22-51 in the reference) as the C ABI sees it."""
+    __slots__ = ("ci", "co", "ms", "k", "d", "causal")
+
+    def __init__(self, ci, co, ms, k, d, causal):
+        self.ci, self.co, self.ms, self.k, self.d, self.causal = int(ci), int(co), int(ms), int(k), int(d), bool(causal)
+
+    def offsets(self):
+        return _lib.tap_offsets(self.k, self.d, self.causal)
+
+    def reach(self):
+        return max(abs(o) for o in self.offsets())
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("wavenet_speech_amd: %s is a CPU tensor; the HIP path needs ROCm device tensors "
+                           "(there is no CPU fallback)" % what)
+    if t.dtype != torch.float32:
+        raise RuntimeError("wavenet_speech_amd: %s must be float32, got %s" % (what, t.dtype))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(x):
+    """device pointer of a tensor / Lease / None"""
+    if x is None:
+        return None
+    if isinstance(x, Lease):
+        return ctypes.c_void_p(x.ptr)
+    return ctypes.c_void_p(x.data_ptr())
+
+
+def _shape(spec, batch, layout):
+    return _lib.BlockShape(batch, layout.length, spec.ci, spec.co, spec.ms, spec.k, spec.d, int(spec.causal),
+                           layout.ld, layout.halo)
+
+
+def _params_struct(tensors):
+    return _lib.BlockParams(*[_p(t) for t in tensors])
+
+
+def _prep_params(tensors, spec):
+    """contiguous fp32 device copies (no-ops for ordinary nn.Parameters) + shape checks"""
+    want = [(spec.co, spec.ci, spec.k), (spec.co,), (spec.co, spec.ci, spec.k), (spec.co,),
+            (spec.co, spec.co), (spec.co,), (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]
+    out = []
+    for t, w in zip(tensors, want):
+        _require_device(t, "parameter")
+        if t.dim() == 3 and len(w) == 2:  # 1x1 Conv1d weights arrive as [Co][Ci][1]
+            t = t[:, :, 0]
+        if tuple(t.shape) != w:
+            raise RuntimeError("wavenet_speech_amd: parameter shape %s, expected %s" % (tuple(t.shape), w))
+        out.append(t.detach().contiguous())
+    return out
+
+
+def _pack_block(lib, shape, params, device):
+    nbytes = lib.wn_block_packed_bytes(ctypes.byref(shape))
+    if nbytes == 0:
+        _lib.check(-1, "wn_block_packed_bytes")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    ps = _params_struct(params)
+    _lib.check(lib.wn_block_pack(ctypes.byref(shape), ctypes.byref(ps), _p(packed), _stream()), "wn_block_pack")
+    return packed
+
+
+def _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dskip, want_dx, layout, batch, device):
+    """bwd-data + bwd-weights of one block; returns (dx lease or None, [10 gradient tensors])"""
+    da, dg = Lease(batch, spec.co, layout, device), Lease(batch, spec.co, layout, device)
+    dx = Lease(batch, spec.ci, layout, device) if want_dx else None
+    _lib.check(lib.wn_block_backward_data(ctypes.byref(shape), _p(packed), _p(dr), _p(dskip), _p(ta), _p(sg),
+                                          _p(da), _p(dg), _p(dx), _stream()), "wn_block_backward_data")
+    k = spec.k
+    grads = [torch.empty(s, dtype=torch.float32, device=device) for s in
+             [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
+              (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]]
+    ws_bytes = lib.wn_block_wgrad_workspace_bytes(ctypes.byref(shape))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+    gs = _params_struct(grads)
+    _lib.check(lib.wn_block_backward_weights(ctypes.byref(shape), _p(x), _p(z), _p(da), _p(dg), _p(dr), _p(dskip),
+                                             ctypes.byref(gs), _p(ws), ws_bytes, _stream()),
+               "wn_block_backward_weights")
+    return dx, grads
+
+
+class _ResidualStackFn(torch.autograd.Function):
+    """The per-layer loop of WaveNet / RawCTCNet / WaveNetClassifier
+    (modules/wavenet.py:98-100, raw_ctcnet.py:138-145, classifier.py:105-112):
+        for l: out, skip = block_l(out); skips_sum = skips_sum + bottleneck_l(skip)
+    with the bottleneck folded into the skip projection by the caller.  Returns skips_sum [B, Ms, L]."""
+
+    @staticmethod
+    def forward(ctx, x, specs, *flat):
+        lib = _lib.load()
+        _require_device(x, "input")
+        n = len(specs)
+        assert len(flat) == n * PARAMS_PER_BLOCK
+        B, C0, L = x.shape
+        if C0 != specs[0].ci:
+            raise RuntimeError("wavenet_speech_amd: input has %d channels, first block expects %d" % (C0, specs[0].ci))
+        dev = x.device
+        layout = SeriesLayout(L, max(s.reach() for s in specs))
+        training = any(ctx.needs_input_grad)
+        cur = Lease(B, C0, layout, dev)
+        load_series(cur.t, x.detach(), layout)
+        ms = specs[0].ms
+        S = fresh_series(B, ms, layout, dev)
+        saved = []
+        zbuf = None
+        for l, spec in enumerate(specs):
+            if spec.ms != ms:
+                raise RuntimeError("wavenet_speech_amd: all blocks of a stack must share out_dim")
+            shape = _shape(spec, B, layout)
+            params = _prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec)
+            packed = _pack_block(lib, shape, params, dev)
+            r = Lease(B, spec.co, layout, dev) if l + 1 < n else None  # the last residual output is never used
+            if training:
+                ta, sg, z = (Lease(B, spec.co, layout, dev) for _ in range(3))
+            else:
+                ta = sg = None
+                if zbuf is None or zbuf.channels != spec.co:
+                    zbuf = Lease(B, spec.co, layout, dev)
+                z = zbuf
+            _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(cur), _p(r), _p(S), 1,
+                                            _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
+            if training:
+                saved.append((cur, ta, sg, z, packed, shape))
+            cur = r
+        ctx.specs, ctx.saved, ctx.layout, ctx.batch = specs, saved, layout, B
+        ctx.param_shapes = [tuple(t.shape) for t in flat]
+        return window(S, ms, layout)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_skips):
+        lib = _lib.load()
+        specs, layout, B = ctx.specs, ctx.layout, ctx.batch
+        dev = d_skips.device
+        dS = Lease(B, specs[0].ms, layout, dev)
+        load_series(dS.t, d_skips, layout)
+        dr = None
+        grads_flat = [None] * (len(specs) * PARAMS_PER_BLOCK)
+        for l in range(len(specs) - 1, -1, -1):
+            spec = specs[l]
+            x, ta, sg, z, packed, shape = ctx.saved[l]
+            want_dx = l > 0 or ctx.needs_input_grad[0]
+            dx, grads = _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dS, want_dx, layout, B, dev)
+            grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
+            dr = dx
+            ctx.saved[l] = None  # release this block's activations to the pool
+        dx0 = window(dr.t, specs[0].ci, layout).clone() if ctx.needs_input_grad[0] else None
+        # 1x1 Conv1d weights come in as [Co][Ci][1]; hand each gradient back in its parameter's own shape
+        grads_flat = [g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
+        return (dx0, None) + tuple(grads_flat)
+
+
+def residual_stack(x, specs, flat_params):
+    """skips_sum of a stack of residual blocks.  flat_params: 10 tensors per block in C-ABI order
+    (w_tanh, b_tanh, w_sigmoid, b_sigmoid, w_res [Co,Co,1], b_res, w_skip [Ms,Co], b_skip, w_proj, b_proj)."""
+    return _ResidualStackFn.apply(x, tuple(specs), *flat_params)
+
+
+class _ResidualBlockFn(torch.autograd.Function):
+    """Stand-alone ResidualBlock.forward (modules/block.py:54-82): returns (residual_out, skip_out)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        lib = _lib.load()
+        _require_device(x, "input")
+        B, C0, L = x.shape
+        if C0 != spec.ci:
+            raise RuntimeError("wavenet_speech_amd: input has %d channels, block expects %d" % (C0, spec.ci))
+        dev = x.device
+        layout = SeriesLayout(L, spec.reach())
+        shape = _shape(spec, B, layout)
+        prm = _prep_params(params, spec)
+        packed = _pack_block(lib, shape, prm, dev)
+        xin = Lease(B, C0, layout, dev)
+        load_series(xin.t, x.detach(), layout)
+        r = Lease(B, spec.co, layout, dev)
+        s = Lease(B, spec.ms, layout, dev)
+        training = any(ctx.needs_input_grad)
+        ta, sg = (Lease(B, spec.co, layout, dev), Lease(B, spec.co, layout, dev)) if training else (None, None)
+        z = Lease(B, spec.co, layout, dev)
+        _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(xin), _p(r), _p(s), 0,
+                                        _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
+        if training:
+            ctx.saved = (xin, ta, sg, z, packed, shape)
+        ctx.spec, ctx.layout, ctx.batch = spec, layout, B
+        ctx.param_shapes = [tuple(t.shape) for t in params]
+        return r.view().contiguous(), s.view().contiguous()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_r, d_s):
+        lib = _lib.load()
+        spec, layout, B = ctx.spec, ctx.layout, ctx.batch
+        dev = d_r.device
+        x, ta, sg, z, packed, shape = ctx.saved
+        dr, ds = Lease(B, spec.co, layout, dev), Lease(B, spec.ms, layout, dev)
+        load_series(dr.t, d_r, layout)
+        load_series(ds.t, d_s, layout)
+        dx, grads = _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, ds, ctx.needs_input_grad[0], layout, B, dev)
+        grads = [g.view(shp) for g, shp in zip(grads, ctx.param_shapes)]
+        dx0 = dx.view().contiguous() if dx is not None else None
+        ctx.saved = None
+        return (dx0, None) + tuple(grads)
+
+
+def residual_block(x, spec, params):
+    """(residual_out, skip_out) of one block; params in C-ABI order with w_res / w_skip as [Co,Co,1] Conv1d weights."""
+    return _ResidualBlockFn.apply(x, spec, *params)
+
+
+class _DilatedConvFn(torch.autograd.Function):
+    """CausalConv1d / NonCausalConv1d forward (modules/conv_ops.py:39-44, 73-79); k=1 gives a 1x1 Conv1d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation, causal):
+        lib = _lib.load()
+        _require_device(x, "input")
+        _require_device(weight, "weight")
+        B, Ci, L = x.shape
+        Co, Ci_w, k = weight.shape
+        if Ci_w != Ci:
+            raise RuntimeError("wavenet_speech_amd: input has %d channels, conv expects %d" % (Ci, Ci_w))
+        dev = x.device
+        reach = max(abs(o) for o in _lib.tap_offsets(k, dilation, causal))
+        layout = SeriesLayout(L, reach)
+        shape = _lib.ConvShape(B, L, Ci, Co, k, int(dilation), int(bool(causal)), layout.ld, layout.halo)
+        nbytes = lib.wn_conv_packed_bytes(ctypes.byref(shape))
+        if nbytes == 0:
+            _lib.check(-1 if k <= _lib.MAX_TAPS else -2, "wn_conv_packed_bytes")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        _lib.check(lib.wn_conv_pack(ctypes.byref(shape), _p(w), _p(b), _p(packed), _stream()), "wn_conv_pack")
+        xin = Lease(B, Ci, layout, dev)
+        load_series(xin.t, x.detach(), layout)
+        y = Lease(B, Co, layout, dev)
+        _lib.check(lib.wn_conv_forward(ctypes.byref(shape), _p(packed), _p(xin), _p(y), _stream()), "wn_conv_forward")
+        if any(ctx.needs_input_grad):
+            ctx.saved = (xin, packed, shape)
+        ctx.layout, ctx.dims, ctx.has_bias = layout, (B, Ci, Co, k), bias is not None
+        return y.view().contiguous()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        xin, packed, shape = ctx.saved
+        layout = ctx.layout
+        B, Ci, Co, k = ctx.dims
+        dev = d_y.device
+        dy = Lease(B, Co, layout, dev)
+        load_series(dy.t, d_y, layout)
+        dx0 = None
+        if ctx.needs_input_grad[0]:
+            dx = Lease(B, Ci, layout, dev)
+            _lib.check(lib.wn_conv_backward_data(ctypes.byref(shape), _p(packed), _p(dy), _p(dx), _stream()),
+                       "wn_conv_backward_data")
+            dx0 = dx.view().contiguous()
+        dw = torch.empty(Co, Ci, k, dtype=torch.float32, device=dev)
+        db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws_bytes = lib.wn_conv_wgrad_workspace_bytes(ctypes.byref(shape))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(lib.wn_conv_backward_weights(ctypes.byref(shape), _p(xin), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes,
+                                                _stream()), "wn_conv_backward_weights")
+        ctx.saved = None
+        return dx0, dw, db, None, None
+
+
+def dilated_conv(x, weight, bias, dilation=1, causal=True):
+    return _DilatedConvFn.apply(x, weight, bias, int(dilation), bool(causal))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# measurement hooks
+# ------------------------------------------------------------------------------------------------------------------
+def profile_enable(on=True):
+    lib = _lib.load()
+    _lib.check(lib.wn_prof_enable(1 if on else 0), "wn_prof_enable")
+
+
+def profile_reset():
+    _lib.check(_lib.load().wn_prof_reset(), "wn_prof_reset")
+
+
+def profile_read():
+    return _lib.profile_read()

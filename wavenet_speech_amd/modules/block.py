@@ -1,0 +1,81 @@
+"""
+Drop-in for the reference's modules/block.py::ResidualBlock (and GatedActivationUnit): identical constructor,
+attributes, parameter names/shapes/registration order; forward = one call into the HIP library.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as HF
+from .conv_ops import CausalConv1d, NonCausalConv1d
+
+
+class GatedActivationUnit(nn.Module):
+    """tanh(x) * sigmoid(y)  (reference modules/block.py:177-188).  Kept for API compatibility; inside
+    ResidualBlock the gate is fused into the dilated-conv kernel's epilogue."""
+
+    def forward(self, x, y):
+        return torch.tanh(x) * torch.sigmoid(y)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' ()'
+
+
+class ResidualBlock(nn.Module):
+    """(residual_out, skip_out) = block(seq)   -- reference modules/block.py:15-82.
+
+    a = conv_tanh(seq), g = conv_sigmoid(seq), z = tanh(a) sigmoid(g)
+    residual_out = conv1x1_residual(z) + residual_proj(seq)      (the projection is a learned Linear, not identity)
+    skip_out     = conv1x1_skip(z)
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_width, dilation, causal=True, conditioning=None):
+        super(ResidualBlock, self).__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_width, self.dilation = kernel_width, dilation
+        self.causal = causal
+        self.conditioning = conditioning is not None
+        conv = CausalConv1d if causal else NonCausalConv1d
+        self.conv_tanh = conv(in_channels, out_channels, kernel_width, dilation=dilation)
+        self.conv_sigmoid = conv(in_channels, out_channels, kernel_width, dilation=dilation)
+        self.conv1x1_residual = nn.Conv1d(out_channels, out_channels, kernel_size=1)
+        self.conv1x1_skip = nn.Conv1d(out_channels, out_channels, kernel_size=1)
+        self.gated_activation = GatedActivationUnit()
+        self.residual_proj = nn.Linear(in_channels, out_channels)
+        self.receptive_field = self.conv_tanh.receptive_field
+
+    def hip_params(self, skip_weight=None, skip_bias=None):
+        """the ten tensors in C-ABI order; the skip projection may be replaced by a folded bottleneck*skip pair"""
+        return [self.conv_tanh.conv1d.weight, self.conv_tanh.conv1d.bias,
+                self.conv_sigmoid.conv1d.weight, self.conv_sigmoid.conv1d.bias,
+                self.conv1x1_residual.weight, self.conv1x1_residual.bias,
+                self.conv1x1_skip.weight if skip_weight is None else skip_weight,
+                self.conv1x1_skip.bias if skip_bias is None else skip_bias,
+                self.residual_proj.weight, self.residual_proj.bias]
+
+    def spec(self, skip_rows=None):
+        return HF.BlockSpec(self.in_channels, self.out_channels,
+                            self.out_channels if skip_rows is None else skip_rows,
+                            self.kernel_width, self.dilation, self.causal)
+
+    def forward(self, seq):
+        return HF.residual_block(seq, self.spec(), self.hip_params())
+
+
+def fold_bottleneck(block, bottleneck):
+    """bottleneck(conv1x1_skip(z)) = (Wb Wk) z + (Wb bk + bb): two tiny [D,C]x[C,C] torch products per step
+    (autograd carries the chain rule back to both parameters), so the stack kernel accumulates skips_sum
+    directly and skip_out never touches HBM."""
+    wb = bottleneck.weight[:, :, 0]
+    wk = block.conv1x1_skip.weight[:, :, 0]
+    return wb @ wk, wb @ block.conv1x1_skip.bias + bottleneck.bias
+
+
+def run_stack(out, blocks, bottlenecks):
+    """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path"""
+    specs, flat = [], []
+    out_dim = bottlenecks[0].out_channels
+    for blk, bott in zip(blocks, bottlenecks):
+        w, b = fold_bottleneck(blk, bott)
+        specs.append(blk.spec(out_dim))
+        flat.extend(blk.hip_params(w, b))
+    return HF.residual_stack(out, specs, flat)
