@@ -49,7 +49,7 @@ typedef enum wn_status {
     WN_ERR_WORKSPACE = -5    /* workspace smaller than wn_*_workspace_bytes() */
 } wn_status;
 
-#define WN_MAX_TAPS 4
+#define WN_MAX_TAPS 8
 #define WN_MAX_CHANNELS 1024
 
 /* Shape of one residual block call.  Mirrors ResidualBlock.__init__ (modules/block.py:22-51)

@@ -199,4 +199,4 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):
         blk(torch.randn(1, 9, 10, device=DEV))        # wrong channel count
     with pytest.raises(RuntimeError):
-        M.CausalConv1d(4, 4, 9).to(DEV)(torch.randn(1, 4, 32, device=DEV))  # kernel_width > WN_MAX_TAPS
+        M.CausalConv1d(4, 4, 9).to(DEV)(torch.randn(1, 4, 32, device=DEV))  # kernel_width 9 > WN_MAX_TAPS (8)

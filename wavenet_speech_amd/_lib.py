@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_longlong, c_
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_amd.so")
 
-MAX_TAPS = 4
+MAX_TAPS = 8
 MAX_CHANNELS = 1024
 
 c_float_p = c_void_p  # device pointers travel as integers

@@ -62,7 +62,8 @@ class Lease(object):
 
     def __init__(self, batch, channels, layout, device):
         cp = round_up(channels, 8)
-        self._key = (str(device), batch, cp, layout.ld)
+        # the zero-padding invariant is tied to the exact valid window, so C, L and halo are part of the key
+        self._key = (str(device), batch, channels, layout.length, layout.halo, layout.ld)
         t = POOL.take(self._key)
         if t is None:
             t = torch.zeros(batch, cp, layout.ld, dtype=torch.float32, device=device)
