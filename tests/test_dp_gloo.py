@@ -1,0 +1,95 @@
+"""CPU, world_size 2, gloo: the data-parallel path (per-rank batch shard + ONE flat gradient all-reduce) gives
+the same gradients as a single process on the concatenated batch.  The model here is the CPU oracle's residual
+block stack (tests may use the oracle); on the GPU the same FlatGradAllReduce object drives RCCL."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wavenet_oracle as O
+from wavenet_speech_amd.parallel import FlatGradAllReduce, shard_bounds
+
+LAYERS = [(6, 6, 2, 1), (6, 6, 2, 2), (6, 6, 2, 4)]
+
+
+def _params():
+    sd = O.random_wavenet_state(6, 2, LAYERS, 6, seed=3)
+    return {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}
+
+
+def _loss(params, x, cot):
+    y = O.wavenet(x, params, LAYERS, False)
+    return (y * cot).sum() / x.shape[0]          # mean over the rank's shard
+
+
+def _data():
+    g = torch.Generator().manual_seed(11)
+    return torch.randn(6, 6, 40, generator=g), torch.randn(6, 6, 40, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    params = _params()
+    sync = FlatGradAllReduce(params.values())
+    x, cot = _data()
+    b, e = shard_bounds(x.shape[0], rank, world)
+    sync.zero()
+    _loss(params, x[b:e], cot[b:e]).backward()
+    sync.reduce()
+    # every gradient is still a view of the flat buffer, and all ranks agree bit for bit
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    flat = sync.flat.clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in params.items()}, out)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_allreduce_matches_single_process(tmp_path):
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    params = _params()
+    x, cot = _data()
+    _loss(params, x, cot).backward()             # single process, whole batch, loss averaged over it
+    for k, p in params.items():
+        if p.grad is None:
+            continue
+        assert O.rel_err(got[k], p.grad) < 1e-5, k
+
+
+def test_flat_buffer_single_process_semantics():
+    params = _params()
+    sync = FlatGradAllReduce(params.values())
+    assert sync.payload_bytes() == 4 * sum(p.numel() for p in params.values())
+    x, cot = _data()
+    sync.zero()
+    _loss(params, x, cot).backward()
+    sync.reduce()                                 # world size 1: no-op
+    ref = _params()
+    _loss(ref, x, cot).backward()
+    for k in params:
+        if ref[k].grad is not None:
+            assert torch.equal(params[k].grad, ref[k].grad)
+    # zero_grad(set_to_none=True) by an optimizer must not break the views
+    for p in params.values():
+        p.grad = None
+    sync.zero()
+    _loss(params, x, cot).backward()
+    sync.reduce()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))

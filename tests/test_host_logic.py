@@ -1,0 +1,110 @@
+"""CPU: the host-side mirror of the reference interface -- constructor signatures, attributes, parameter names /
+shapes / order (the checkpoint contract), init rules, layout helpers, the no-CPU-fallback rule."""
+import pytest
+import torch
+
+from tests import goldenio
+from wavenet_speech_amd import modules as M
+from wavenet_speech_amd.modules import block as B
+from wavenet_speech_amd.parallel import shard_bounds
+from wavenet_speech_amd.series import SeriesLayout, round_up
+
+
+def _build(g):
+    m = g.meta
+    kind = m["kind"]
+    if kind == "conv":
+        return (M.CausalConv1d if m["causal"] else M.NonCausalConv1d)(m["cin"], m["cout"], m["k"], dilation=m["d"])
+    if kind == "block":
+        return M.ResidualBlock(m["cin"], m["cout"], m["k"], m["d"], causal=m["causal"])
+    if kind == "wavenet":
+        return M.WaveNet(m["in_dim"], m["entry_kwidth"], m["layers"], m["out_dim"], softmax=m["softmax"])
+    if kind == "rawctc":
+        return M.RawCTCNet(m["num_features"], m["feature_kwidth"], m["num_labels"], m["layers"], m["out_dim"],
+                           input_kernel_size=m["input_kernel_size"], input_dilation=m["input_dilation"],
+                           positions=m["positions"], softmax=m["softmax"], causal=m["causal"])
+    if kind == "classifier":
+        return M.WaveNetClassifier(m["in_dim"], m["num_labels"], m["layers"], m["out_dim"],
+                                   pool_kernel_size=m["pool_kernel_size"], input_kernel_size=m["input_kernel_size"],
+                                   input_dilation=m["input_dilation"], softmax=m["softmax"])
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("name", goldenio.names())
+def test_state_dict_contract_matches_reference(name):
+    """same keys, same ORDER (optimizer param groups), same shapes as the reference module's state_dict"""
+    g = goldenio.load(name)
+    mod = _build(g)
+    ours = [(k, tuple(v.shape)) for k, v in mod.state_dict().items()]
+    ref = [(k, tuple(v.shape)) for k, v in g.sd.items()]
+    assert ours == ref
+    assert [k for k, _ in mod.named_parameters()] == list(g.grads.keys())
+    mod.load_state_dict(g.sd, strict=True)
+
+
+def test_public_attributes():
+    blk = M.ResidualBlock(4, 5, 3, 7, causal=False)
+    assert (blk.in_channels, blk.out_channels, blk.kernel_width, blk.dilation, blk.causal, blk.conditioning) == \
+        (4, 5, 3, 7, False, False)
+    assert blk.receptive_field == 3 + (7 - 1) * (3 - 1)
+    assert isinstance(blk.residual_proj, torch.nn.Linear)          # learned projection, not identity
+    conv = M.CausalConv1d(3, 4, 5, dilation=3)
+    assert conv.padding == 12 and conv.receptive_field == 5 + 2 * 4
+    assert M.NonCausalConv1d(3, 4, 2, dilation=3).padding == 2
+    layers = [(8, 8, 2, 1), (8, 8, 2, 2)]
+    net = M.WaveNet(6, 2, layers, 10, softmax=False)
+    assert (net.in_dim, net.entry_kwidth, net.num_layers, net.out_dim, net.softmax, net.layers) == (6, 2, 2, 10, False, layers)
+    raw = M.RawCTCNet(8, 3, 5, layers, 8, positions=True)
+    assert raw.positions and not raw.causal and raw.num_labels == 5 and hasattr(raw, "positions_conv1x1")
+    clf = M.WaveNetClassifier(8, 5, layers, 8, pool_kernel_size=3)
+    assert clf.pool_kernel_size == 3 and clf.pool_padding == 0
+
+
+def test_reference_init_rules():
+    torch.manual_seed(0)
+    net = M.WaveNet(8, 2, [(8, 8, 2, 1)], 8)
+    assert float(net.convolutions[0].conv_tanh.conv1d.bias.abs().max()) == 0.0     # biases zeroed
+    assert float(net.bottlenecks[0].bias.abs().max()) == 0.0
+    w = net.bottlenecks[0].weight[:, :, 0]
+    assert not torch.allclose(w, torch.eye(8))        # the reference's identity init is dead code for 3-D weights
+    raw = M.RawCTCNet(8, 3, 5, [(8, 8, 2, 1)], 8)
+    wb = raw.bottlenecks[0].weight[:, :, 0]
+    assert float((wb - torch.eye(8)).abs().max()) < 1e-3   # RawCTCNet DOES identity-init (+1e-4 noise) bottlenecks
+    assert 0 < float(raw.input_block.conv_tanh.conv1d.bias.abs().max()) < 1e-3
+
+
+def test_cpu_tensors_raise_no_fallback():
+    for mod, x in ((M.ResidualBlock(4, 4, 2, 1), torch.randn(1, 4, 8)),
+                   (M.CausalConv1d(4, 4, 2), torch.randn(1, 4, 8)),
+                   (M.WaveNet(4, 2, [(4, 4, 2, 1)], 4), torch.randn(1, 4, 8))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod(x)
+
+
+def test_bottleneck_folding_is_exact_algebra():
+    """(Wb Wk) z + (Wb bk + bb) == bottleneck(conv1x1_skip(z)) -- checked in fp64 on CPU"""
+    torch.manual_seed(1)
+    blk = M.ResidualBlock(6, 6, 2, 1).double()
+    bott = torch.nn.Conv1d(6, 9, 1).double()
+    z = torch.randn(2, 6, 11, dtype=torch.float64)
+    w, b = B.fold_bottleneck(blk, bott)
+    lhs = torch.einsum("oc,bcl->bol", w, z) + b.view(1, -1, 1)
+    rhs = bott(blk.conv1x1_skip(z))
+    assert torch.allclose(lhs, rhs, atol=1e-12)
+
+
+def test_series_layout_rule():
+    lay = SeriesLayout(16000, 512)
+    assert (lay.length, lay.halo, lay.ld) == (16000, 512, 17024)
+    lay = SeriesLayout(1, 0)
+    assert (lay.halo, lay.ld) == (0, 128)
+    assert round_up(5, 8) == 8 and round_up(16, 8) == 16
+
+
+def test_shard_bounds_cover_the_batch():
+    for gb, w in ((128, 8), (10, 4), (3, 4), (16, 1)):
+        spans = [shard_bounds(gb, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [e - b for b, e in spans]
+        assert max(sizes) - min(sizes) <= 1

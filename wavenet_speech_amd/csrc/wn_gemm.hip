@@ -16,9 +16,11 @@
 //    mask-free.  The four floats of that load are the B operands of the four N-tiles.
 //  * weights are pre-packed in fragment order (wn_pack.hip): one global_load_dwordx4 per lane
 //    gives the A operands of four consecutive k-steps of one 32-row tile, fully coalesced.
-//  * register double-buffering one k-block (8 channels = 4 MFMA k-steps x MT x 4 tiles) ahead.
+//  * register prefetch: weights one k-block (8 channels = 4 MFMA k-steps x MT x 4 tiles) ahead, activations three.
 //  * blockIdx -> (column tile, slab) mapping keeps all slabs of one column tile on one XCD
 //    (blocks b and b+8 share an XCD/L2), so the activation tile is fetched into one L2 only.
+#include <cstdlib>
+
 #include "wn_kernels.h"
 
 namespace wn {
@@ -27,16 +29,26 @@ __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int MT>
-struct Frag {
-    f32x4 a[MT];  // a[m][q]: A operand of k-step q for row-tile m
-    f32x4 b[4];   // b[q][t]: B operand of k-step q for column-tile t
-};
+// B operand of one k-step: NT consecutive time steps of one channel row (one 16- or 8-byte load per lane)
+template <int NT> struct BVec;
+template <> struct BVec<4> { typedef f32x4u load_t; typedef f32x4 reg_t; };
+template <> struct BVec<2> { typedef float __attribute__((ext_vector_type(2), aligned(4))) load_t;
+                             typedef float __attribute__((ext_vector_type(2))) reg_t; };
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
+// MT x NT accumulator tiles per wave (rows x 32*NT time steps); PFB = how many k-blocks ahead the activation
+// (B) operand is prefetched (weights are always one k-block ahead: they are L2 hits); WPS = waves per SIMD the
+// register budget is sized for.
+template <int MT, int NT, int EPI, int PFB, int WPS>
+__global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) {
+    typedef typename BVec<NT>::load_t bload_t;
+    typedef typename BVec<NT>::reg_t breg_t;
+    constexpr int COLS = 32 * NT;
     const int lane = threadIdx.x;
     const int n = lane & 31, h = lane >> 5;
+#ifdef WN_STAMPS
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_t1 = 0, st_t2 = 0;
+#endif
 
     // ---- XCD-aware work mapping -------------------------------------------------------------
     // grid = nslab * ncol8 (ncol8 = ncol rounded up to 8).  Workgroups id and id+8 share an XCD:
@@ -47,38 +59,42 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
     const int coltile = (local / a.nslab) * 8 + xcd;
     if (coltile >= a.ncol) return;
     const int b = coltile / a.tiles_per_row;
-    const int t0 = (coltile - b * a.tiles_per_row) * kColTile;
+    const int t0 = (coltile - b * a.tiles_per_row) * COLS;
     const GemmSlab sl = a.slab[slab_i];
     const int ld = a.ld;
 
     // ---- accumulators, initialised with the bias of their row --------------------------------
-    f32x16 acc[MT][4];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r, h)] : 0.0f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[m][t][r] = bv;
+            for (int t = 0; t < NT; ++t) acc[m][t][r] = bv;
         }
     }
 
     // ---- K loop over the slab's segments, one k-block (8 channel rows) per step ---------------
-    int nkb_total = 0;
-    for (int s = 0; s < sl.nseg; ++s) nkb_total += a.seg[s].nkb;
+    int nkb = 0;
+    for (int s = 0; s < sl.nseg; ++s) nkb += a.seg[s].nkb;
 
     const float* wp = a.wpacked + sl.woff + lane * 4;
-    const long colbase = (long)a.halo + t0 + 4 * n;
+    const long colbase = (long)a.halo + t0 + NT * n;
     int seg = 0;
     int seg_left = a.seg[0].nkb;
     const float* bp = a.seg[0].base + ((long)b * a.seg[0].cp + 4 * h) * ld + colbase + a.seg[0].off;
 
-    auto load = [&](Frag<MT>& f) {
+    f32x4 A[2][MT];    // A[slot][m][q]: A operand of k-step q for row-tile m
+    breg_t B[4][4];    // B[slot][q][t]: B operand of k-step q for column-tile t
+    auto loadA = [&](f32x4 (&dst)[MT]) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const f32x4*>(wp + m * 256);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.b[q] = *reinterpret_cast<const f32x4u*>(bp + (long)q * ld);
+        for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const f32x4*>(wp + m * 256);
         wp += MT * 256;
+    };
+    auto loadB = [&](breg_t (&dst)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bload_t*>(bp + (long)q * ld);
         bp += 8 * (long)ld;
         if (--seg_left == 0) {
             ++seg;
@@ -88,40 +104,63 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
             }
         }
     };
-    auto compute = [&](const Frag<MT>& f) {
+    auto compute = [&](const f32x4 (&fa)[MT], const breg_t (&fb)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[m][q], f.b[q][t], acc[m][t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][q], fb[q][t], acc[m][t], 0, 0, 0);
     };
 
-    Frag<MT> f0, f1;
-    load(f0);
-    for (int g = 0; g < nkb_total; g += 2) {
-        const bool has1 = g + 1 < nkb_total;
-        if (has1) load(f1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block
-        compute(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has1) {
-            if (g + 2 < nkb_total) load(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(f1);
-            __builtin_amdgcn_sched_barrier(0);
+    loadA(A[0]);
+#pragma unroll
+    for (int p = 0; p < PFB; ++p)
+        if (p < nkb) loadB(B[p]);
+#ifdef WN_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    st_t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    for (int g0 = 0; g0 < nkb; g0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = g0 + j;
+            if (g < nkb) {
+                if (g + 1 < nkb) loadA(A[(j + 1) & 1]);
+                if (g + PFB < nkb) loadB(B[(j + PFB) & 3]);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block
+                compute(A[j & 1], B[j & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
+#ifdef WN_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    st_t2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    struct StampOut {
+        unsigned long long* p; unsigned long long t0, r0, t1, t2; int lane;
+        __device__ ~StampOut() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the drain of the epilogue's stores
+            if (p && lane == 0) {
+                p[0] = t0; p[1] = t1; p[2] = t2; p[3] = __builtin_amdgcn_s_memtime();
+                p[4] = r0; p[5] = __builtin_amdgcn_s_memrealtime();
+                p[6] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+                p[7] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+            }
+        }
+    } stamp_out{a.stamps ? a.stamps + 8ull * blockIdx.x : nullptr, st_t0, st_r0, st_t1, st_t2, lane};
+#endif
     // ---- epilogue -----------------------------------------------------------------------------
-    const int c0 = t0 + 4 * n;  // first of this lane's four columns
+    const int c0 = t0 + NT * n;  // first of this lane's NT columns
     if (c0 >= a.L) return;
-    const bool v1 = c0 + 1 < a.L, v2 = c0 + 2 < a.L, v3 = c0 + 3 < a.L;
-    auto clip = [&](f32x4 v) {  // columns >= L stay zero (the layout's zero tail)
-        if (!v1) v[1] = 0.0f;
-        if (!v2) v[2] = 0.0f;
-        if (!v3) v[3] = 0.0f;
+    auto clip = [&](breg_t v) {  // columns >= L stay zero (the layout's zero tail)
+#pragma unroll
+        for (int t = 1; t < NT; ++t)
+            if (c0 + t >= a.L) v[t] = 0.0f;
         return v;
     };
 
@@ -134,11 +173,14 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
                 const int row = sl.row0 + 32 * m + rowof(r, h);
                 if (row < d.rows) {
                     float* p = d.base + ((long)b * d.cp + row) * ld + colbase;
-                    f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-                    if (d.accumulate) v += *reinterpret_cast<const f32x4*>(p);
-                    *reinterpret_cast<f32x4*>(p) = clip(v);
+                    breg_t v;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r];
+                    if (d.accumulate) v += *reinterpret_cast<const breg_t*>(p);
+                    *reinterpret_cast<breg_t*>(p) = clip(v);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else if constexpr (EPI == EPI_GATE) {
         // tiles (2i, 2i+1) hold a and g of the same 32 channels
@@ -148,9 +190,9 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int ch = sl.row0 + 32 * i + rowof(r, h);
                 if (ch < a.gate_rows) {
-                    f32x4 vt, vs, vz;
+                    breg_t vt, vs, vz;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         const float tt = tanhf(acc[2 * i][t][r]);
                         const float ss = sigmoid_f(acc[2 * i + 1][t][r]);
                         vt[t] = tt;
@@ -158,13 +200,14 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
                         vz[t] = tt * ss;
                     }
                     const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
-                    *reinterpret_cast<f32x4*>(a.z + o) = clip(vz);
+                    *reinterpret_cast<breg_t*>(a.z + o) = clip(vz);
                     if (a.ta) {
-                        *reinterpret_cast<f32x4*>(a.ta + o) = clip(vt);
-                        *reinterpret_cast<f32x4*>(a.sg + o) = clip(vs);
+                        *reinterpret_cast<breg_t*>(a.ta + o) = clip(vt);
+                        *reinterpret_cast<breg_t*>(a.sg + o) = clip(vs);
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {  // EPI_DGATE: acc = dz ; da = dz*sg*(1-ta^2), dg = dz*ta*sg*(1-sg)
 #pragma unroll
@@ -174,42 +217,79 @@ __global__ __launch_bounds__(64) void series_gemm_kernel(const GemmArgs a) {
                 const int ch = sl.row0 + 32 * m + rowof(r, h);
                 if (ch < a.gate_rows) {
                     const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
-                    const f32x4 vt = *reinterpret_cast<const f32x4*>(a.ta + o);
-                    const f32x4 vs = *reinterpret_cast<const f32x4*>(a.sg + o);
-                    f32x4 va, vg;
+                    const breg_t vt = *reinterpret_cast<const breg_t*>(a.ta + o);
+                    const breg_t vs = *reinterpret_cast<const breg_t*>(a.sg + o);
+                    breg_t va, vg;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         const float dz = acc[m][t][r];
                         va[t] = dz * vs[t] * (1.0f - vt[t] * vt[t]);
                         vg[t] = dz * vt[t] * vs[t] * (1.0f - vs[t]);
                     }
-                    *reinterpret_cast<f32x4*>(a.da + o) = clip(va);
-                    *reinterpret_cast<f32x4*>(a.dg + o) = clip(vg);
+                    *reinterpret_cast<breg_t*>(a.da + o) = clip(va);
+                    *reinterpret_cast<breg_t*>(a.dg + o) = clip(vg);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int MT, int EPI>
-static hipError_t launch_one(const GemmArgs& a, hipStream_t st) {
+#ifdef WN_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void wn_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+extern "C" unsigned wn_debug_last_grid = 0;
+#endif
+
+template <int MT, int NT, int EPI, int PFB, int WPS>
+static hipError_t launch_one(GemmArgs a, hipStream_t st) {
+#ifdef WN_STAMPS
+    a.stamps = g_stamp_buf;
+#endif
+    a.tiles_per_row = (a.L + 32 * NT - 1) / (32 * NT);
+    a.ncol = a.B * a.tiles_per_row;
     const int ncol8 = (a.ncol + 7) / 8 * 8;
     const unsigned grid = (unsigned)(a.nslab * ncol8);
-    hipLaunchKernelGGL((series_gemm_kernel<MT, EPI>), dim3(grid), dim3(64), 0, st, a);
+#ifdef WN_STAMPS
+    wn_debug_last_grid = grid;
+#endif
+    hipLaunchKernelGGL((series_gemm_kernel<MT, NT, EPI, PFB, WPS>), dim3(grid), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 
+// Variant 0 (default): MT x 4 tiles, B prefetched 3 k-blocks ahead, one wave per SIMD.
+// WN_GEMM_VARIANT=1 selects prefetch depth 1 for A/B measurements (tools/gemm_sweep.py).
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_GEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int EPI>
+static hipError_t launch_epi(int MT, const GemmArgs& a, hipStream_t st) {
+    const int v = gemm_variant();
+    if (MT == 4) {
+        // measured on MI355X (tools/gemm_sweep.py, profiles/r01/gemm_variants.txt): prefetch depth 1 vs 3 is a
+        // tie; 64-column tiles at two waves per SIMD (NT=2) were 20-30 % slower and are not instantiated.
+        if (v == 1) return launch_one<4, 4, EPI, 1, 1>(a, st);
+        return launch_one<4, 4, EPI, 3, 1>(a, st);
+    }
+    if (MT == 2) return launch_one<2, 4, EPI, 3, 2>(a, st);
+    if constexpr (EPI != EPI_GATE) {
+        if (MT == 1) return launch_one<1, 4, EPI, 3, 2>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm(int MT, int epi, const GemmArgs& a, hipStream_t st) {
-    if (a.nslab <= 0 || a.ncol <= 0) return hipSuccess;
-    switch (epi * 8 + MT) {
-        case EPI_LINEAR * 8 + 1: return launch_one<1, EPI_LINEAR>(a, st);
-        case EPI_LINEAR * 8 + 2: return launch_one<2, EPI_LINEAR>(a, st);
-        case EPI_LINEAR * 8 + 4: return launch_one<4, EPI_LINEAR>(a, st);
-        case EPI_GATE * 8 + 2: return launch_one<2, EPI_GATE>(a, st);
-        case EPI_GATE * 8 + 4: return launch_one<4, EPI_GATE>(a, st);
-        case EPI_DGATE * 8 + 1: return launch_one<1, EPI_DGATE>(a, st);
-        case EPI_DGATE * 8 + 2: return launch_one<2, EPI_DGATE>(a, st);
-        case EPI_DGATE * 8 + 4: return launch_one<4, EPI_DGATE>(a, st);
+    if (a.nslab <= 0 || a.B <= 0 || a.L <= 0) return hipSuccess;
+    switch (epi) {
+        case EPI_LINEAR: return launch_epi<EPI_LINEAR>(MT, a, st);
+        case EPI_GATE: return launch_epi<EPI_GATE>(MT, a, st);
+        case EPI_DGATE: return launch_epi<EPI_DGATE>(MT, a, st);
     }
     return hipErrorInvalidValue;
 }

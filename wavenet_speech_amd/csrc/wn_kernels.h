@@ -64,8 +64,9 @@ struct GemmArgs {
     int gate_rows;    // Co
     int nslab;
     int B, L, ld, halo;
-    int tiles_per_row;  // ceil(L / 128)
+    int tiles_per_row;  // ceil(L / column tile)
     int ncol;           // B * tiles_per_row
+    unsigned long long* stamps;  // diagnostic build (-DWN_STAMPS) only: 8 words per workgroup
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_DGATE = 2 };
