@@ -184,22 +184,33 @@ def block_stack(out, skips_sum, sd, layers, causal, impl="taps",
     return out, skips_sum
 
 
+def _leaky(x, slopes, key):
+    """LeakyReLU(0.01).  `slopes` (optional dict key -> tensor of per-element slopes 1 / 0.01) pins the activation
+    pattern: LeakyReLU is not differentiable at 0, and two fp32 evaluations of the same network can put a
+    pre-activation that is ~0 on opposite sides of the kink, which changes that element's gradient by 99 %.
+    Tests that compare gradients of deep models capture the pattern of the implementation under test and replay it
+    here, so that the comparison is about arithmetic, not about which side of a tie was taken."""
+    if slopes is not None and key in slopes:
+        return x * slopes[key]
+    return F.leaky_relu(x, 0.01)
+
+
 def channel_softmax(x):
     """reshape_in -> F.softmax (implicit dim=1 on a 2-D tensor = channels) -> reshape_out
     (modules/wavenet.py:108-109, modules/conv_ops.py:91-101)."""
     return torch.softmax(x, dim=1)
 
 
-def wavenet(signal, sd, layers, softmax, impl="taps"):
+def wavenet(signal, sd, layers, softmax, impl="taps", slopes=None):
     """WaveNet.forward (modules/wavenet.py:88-111): entry CausalConv1d(d=1) -> causal block stack ->
     LeakyReLU(0.01), 1x1, LeakyReLU(0.01), 1x1 on skips_sum (:67-71,:103) -> optional softmax."""
     out = dilated_conv(signal, sd["entry_conv1d.conv1d.weight"], sd["entry_conv1d.conv1d.bias"], 1, True, impl)
     out_dim = sd["bottlenecks.0.weight"].shape[0]
     skips = torch.zeros(signal.shape[0], out_dim, signal.shape[2], dtype=signal.dtype)
     _, skips = block_stack(out, skips, sd, layers, True, impl)
-    y = F.leaky_relu(skips, 0.01)
+    y = _leaky(skips, slopes, "output_stack.0")
     y = conv1x1(y, sd["output_stack.1.weight"], sd["output_stack.1.bias"])
-    y = F.leaky_relu(y, 0.01)
+    y = _leaky(y, slopes, "output_stack.2")
     y = conv1x1(y, sd["output_stack.3.weight"], sd["output_stack.3.bias"])
     return channel_softmax(y) if softmax else y
 
@@ -216,37 +227,37 @@ def _input_block_and_stack(out, sd, layers, causal, impl):
     return skips
 
 
-def _output_block(skips, sd):
-    y = F.leaky_relu(skips, 0.01)
+def _output_block(skips, sd, slopes=None):
+    y = _leaky(skips, slopes, "output_block.0")
     y = conv1x1(y, sd["output_block.1.weight"], sd["output_block.1.bias"])
-    y = F.leaky_relu(y, 0.01)
+    y = _leaky(y, slopes, "output_block.2")
     return conv1x1(y, sd["output_block.3.weight"], sd["output_block.3.bias"])
 
 
 def raw_ctcnet(seq, sd, layers, feature_kwidth, input_dilation=1, positions=False,
-               softmax=True, causal=False, impl="taps"):
+               softmax=True, causal=False, impl="taps", slopes=None):
     """RawCTCNet.forward (modules/raw_ctcnet.py:117-153).
     feature_layer = Conv1d(1,F,k,padding=k-1) [length grows to L+k-1, :57-61,:128], LeakyReLU, 1x1, LeakyReLU;
     optional positions: out += Hardtanh(Conv1x1(arange(L'))) (:131-135)."""
     kf = feature_kwidth
     out = F.conv1d(seq, sd["feature_layer.0.weight"], sd["feature_layer.0.bias"], padding=kf - 1)
-    out = F.leaky_relu(out, 0.01)
-    out = F.leaky_relu(conv1x1(out, sd["feature_layer.2.weight"], sd["feature_layer.2.bias"]), 0.01)
+    out = _leaky(out, slopes, "feature_layer.1")
+    out = _leaky(conv1x1(out, sd["feature_layer.2.weight"], sd["feature_layer.2.bias"]), slopes, "feature_layer.3")
     if positions:
         pos = torch.arange(0., out.shape[2], dtype=out.dtype).view(1, 1, -1)
         out = out + F.hardtanh(conv1x1(pos, sd["positions_conv1x1.0.weight"], sd["positions_conv1x1.0.bias"]))
     sd = dict(sd)
     sd["__input_dilation__"] = input_dilation
-    y = _output_block(_input_block_and_stack(out, sd, layers, causal, impl), sd)
+    y = _output_block(_input_block_and_stack(out, sd, layers, causal, impl), sd, slopes)
     return channel_softmax(y) if softmax else y
 
 
-def wavenet_classifier(seq, sd, layers, pool_kernel_size=2, input_dilation=1, softmax=True, impl="taps"):
+def wavenet_classifier(seq, sd, layers, pool_kernel_size=2, input_dilation=1, softmax=True, impl="taps", slopes=None):
     """WaveNetClassifier.forward (modules/classifier.py:91-120): AvgPool1d(pool) -> non-causal stack."""
     out = F.avg_pool1d(seq, pool_kernel_size)
     sd = dict(sd)
     sd["__input_dilation__"] = input_dilation
-    y = _output_block(_input_block_and_stack(out, sd, layers, False, impl), sd)
+    y = _output_block(_input_block_and_stack(out, sd, layers, False, impl), sd, slopes)
     return channel_softmax(y) if softmax else y
 
 
@@ -258,6 +269,20 @@ def wavenet_classifier(seq, sd, layers, pool_kernel_size=2, input_dilation=1, so
 def one_hot_encoding(seq, num_indices):
     """modules/fns.py:6-15: (B, L) long -> (B, num_indices, L) float one-hot."""
     return torch.zeros(seq.size(0), num_indices, seq.size(1)).scatter_(1, seq.unsqueeze(1), 1.)
+
+
+def capture_leaky_slopes(model):
+    """Register forward-pre-hooks on every nn.LeakyReLU of `model`; returns (slopes dict, remove()).  After a forward
+    pass slopes["<module name>"] holds the per-element slope (1 where the input was > 0, else 0.01) on the CPU."""
+    import torch.nn as nn
+    slopes, handles = {}, []
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.LeakyReLU):
+            def hook(_m, inp, name=name, ns=mod.negative_slope):
+                xin = inp[0].detach()
+                slopes[name] = torch.where(xin > 0, torch.ones_like(xin), torch.full_like(xin, ns)).cpu()
+            handles.append(mod.register_forward_pre_hook(hook))
+    return slopes, lambda: [h.remove() for h in handles]
 
 
 def rel_err(a, b):

@@ -1,0 +1,171 @@
+"""
+GPU parity at BASELINE.json's sizes (-m gpu).
+
+* configs[2] (the metric's config): WaveNet 256 ch x 30 blocks (3 x dilation 1..512), L=16000 -- one full utterance
+  against the CPU oracle (forward + every gradient), then size-independent properties at the full batch of 16:
+  causality (a prefix of the output depends only on the same prefix of the input), batch additivity of the weight
+  gradients, determinism (bitwise identical reruns).
+* configs[1] shape: RawCTCNet 128 ch, 10 blocks 1..512 (+ input block), L=4096 (computed in fp32 here: the stated
+  1e-4 parity bar is not reachable with bf16 storage).
+* configs[4] width: 512 channels (multi-slab / multi-tile kernels) at a reduced depth/length the oracle finishes in seconds.
+Tolerance 1e-4 relative (north_star).
+
+Conditioning note (measured): with the reference's random init the residual stream grows ~sqrt(2)
+per block (residual_proj is a kaiming-uniform Linear, not identity) and reaches ~1e5 after 30 blocks; two CPU fp32
+summation orders of the SAME math then differ by ~5e-4 and each is ~5e-4 from an fp64 evaluation.  The 1e-4 bar is
+therefore applied with a conditioned residual path (proj ~ I, as in a trained network; fp32-vs-fp64 error ~1e-6), and
+for the reference init the HIP path is required to be as close to the fp64 truth as the CPU fp32 path is.
+"""
+import pytest
+import torch
+
+from oracle import wavenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _layers(c, cycles):
+    return [(c, c, 2, 2 ** i) for _ in range(cycles) for i in range(10)]
+
+
+def _wavenet(c, layers, seed=0, conditioned=True):
+    from wavenet_speech_amd.modules.wavenet import WaveNet
+    torch.manual_seed(seed)
+    net = WaveNet(c, 2, layers, c, softmax=False)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn(p.shape))
+        if conditioned:
+            for blk in net.convolutions:
+                blk.residual_proj.weight.copy_(torch.eye(blk.out_channels, blk.in_channels)
+                                               + 0.02 * torch.randn(blk.out_channels, blk.in_channels))
+                blk.conv1x1_residual.weight.mul_(0.3)
+    return net
+
+
+def _onehot(b, c, l, seed):
+    g = torch.Generator().manual_seed(seed)
+    return O.one_hot_encoding(torch.randint(0, c, (b, l), generator=g), c), torch.randn(b, c, l, generator=g)
+
+
+def test_cfg3_one_utterance_vs_oracle():
+    c, L = 256, 16000
+    layers = _layers(c, 3)
+    net = _wavenet(c, layers)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x, cot = _onehot(1, c, L, 1)
+    net = net.to(DEV)
+    slopes, remove = O.capture_leaky_slopes(net)     # pin the LeakyReLU pattern (see oracle._leaky)
+    y1 = net(x.to(DEV))
+    remove()
+    (y1 * cot.to(DEV)).sum().backward()
+    with torch.no_grad():
+        assert O.rel_err(y1.detach().cpu(), O.wavenet(x, sd, layers, False, impl="aten")) < TOL   # plain forward
+    y0 = O.wavenet(x, sd, layers, False, impl="aten", slopes=slopes)
+    (y0 * cot).sum().backward()
+    assert O.rel_err(y1.detach().cpu(), y0) < TOL
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:
+            continue
+        e = O.rel_err(p.grad.cpu(), sd[k].grad)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < TOL, worst
+
+
+def test_cfg3_reference_init_is_as_close_to_fp64_as_the_cpu_fp32_path():
+    c, L = 256, 16000
+    layers = _layers(c, 3)
+    net = _wavenet(c, layers, seed=7, conditioned=False)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, _ = _onehot(1, c, L, 8)
+    with torch.no_grad():
+        y64 = O.wavenet(x.double(), {k: v.double() for k, v in sd.items()}, layers, False, impl="taps")
+        y_cpu = O.wavenet(x, sd, layers, False, impl="aten")
+        y_hip = net.to(DEV)(x.to(DEV)).cpu()
+    e_cpu, e_hip = O.rel_err(y_cpu.double(), y64), O.rel_err(y_hip.double(), y64)
+    print("reference init, 30 blocks: CPU fp32 vs fp64 %.2e, HIP fp32 vs fp64 %.2e" % (e_cpu, e_hip))
+    assert e_hip < max(TOL, 2.0 * e_cpu)
+
+
+def test_cfg3_full_batch_properties():
+    c, L, B = 256, 16000, 16
+    layers = _layers(c, 3)
+    net = _wavenet(c, layers, seed=1).to(DEV)
+    x, cot = _onehot(B, c, L, 2)
+    x, cot = x.to(DEV), cot.to(DEV)
+
+    def grads(xs, cs):
+        net.zero_grad(set_to_none=True)
+        y = net(xs)
+        (y * cs).sum().backward()
+        return y.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    y, g_all = grads(x, cot)
+    y2, g_again = grads(x, cot)
+    assert torch.equal(y, y2) and all(torch.equal(g_all[k], g_again[k]) for k in g_all)   # deterministic
+    # causality: the first 4096 output steps only see the first 4096 input steps (bitwise: same tiles, same order)
+    with torch.no_grad():
+        y_prefix = net(x[:, :, :4096].contiguous())
+    assert torch.equal(y_prefix, y[:, :, :4096])
+    # batch additivity: grads(16) == grads(first 8) + grads(last 8) up to fp32 summation order
+    _, g_a = grads(x[:8].contiguous(), cot[:8].contiguous())
+    _, g_b = grads(x[8:].contiguous(), cot[8:].contiguous())
+    for k in g_all:
+        assert O.rel_err((g_a[k] + g_b[k]).cpu(), g_all[k].cpu()) < 1e-5, k
+    # per-utterance independence: utterance 5 alone gives the same output rows
+    with torch.no_grad():
+        y5 = net(x[5:6].contiguous())
+    assert torch.equal(y5[0], y[5])
+
+
+def test_cfg2_shape_raw_ctcnet_vs_oracle():
+    from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+    torch.manual_seed(2)
+    layers = [(128, 128, 2, 2 ** i) for i in range(10)]
+    net = RawCTCNet(128, 3, 5, layers, 128, softmax=False, causal=False)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 1, 4096, generator=g)
+    cot = torch.randn(4, 5, 4098, generator=g)
+    net = net.to(DEV)
+    slopes, remove = O.capture_leaky_slopes(net)
+    xg = x.to(DEV).requires_grad_(True)
+    y1 = net(xg)
+    remove()
+    assert tuple(y1.shape) == (4, 5, 4098)
+    (y1 * cot.to(DEV)).sum().backward()
+    with torch.no_grad():
+        assert O.rel_err(y1.detach().cpu(), O.raw_ctcnet(x, sd, layers, 3, 1, False, False, False, impl="aten")) < TOL
+    y0 = O.raw_ctcnet(x, sd, layers, 3, 1, False, False, False, impl="aten", slopes=slopes)
+    (y0 * cot).sum().backward()
+    assert O.rel_err(y1.detach().cpu(), y0) < TOL
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:      # the last block's residual output is unused: autograd gives None, the HIP path zeros
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert O.rel_err(p.grad.cpu(), sd[k].grad) < TOL, k
+
+
+def test_cfg5_width_512_channels_vs_oracle():
+    c, L = 512, 4800
+    layers = [(c, c, 2, d) for d in (1, 16, 512, 2, 256, 64)]
+    net = _wavenet(c, layers, seed=4)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x, cot = torch.randn(1, c, L, generator=g), torch.randn(1, c, L, generator=g)
+    net = net.to(DEV)
+    slopes, remove = O.capture_leaky_slopes(net)
+    y1 = net(x.to(DEV))
+    remove()
+    (y1 * cot.to(DEV)).sum().backward()
+    y0 = O.wavenet(x, sd, layers, False, impl="aten", slopes=slopes)
+    (y0 * cot).sum().backward()
+    assert O.rel_err(y1.detach().cpu(), y0) < TOL
+    for k, p in net.named_parameters():
+        if sd[k].grad is not None:
+            assert O.rel_err(p.grad.cpu(), sd[k].grad) < TOL, k

@@ -147,12 +147,15 @@ def test_wavenet_vs_oracle_mid_size():
     q = torch.randint(0, 64, (2, 2000))
     x = O.one_hot_encoding(q, 64)
     cot = torch.randn(2, 64, 2000)
-    sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    y0 = O.wavenet(x, sdl, layers, False, impl="aten")
-    (y0 * cot).sum().backward()
     net = net.to(DEV)
+    slopes, remove = O.capture_leaky_slopes(net)     # replay the HIP model's LeakyReLU pattern in the oracle
     y1 = net(x.to(DEV))
+    remove()
     (y1 * cot.to(DEV)).sum().backward()
+    sdl = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y0 = O.wavenet(x, sdl, layers, False, impl="aten", slopes=slopes)
+    (y0 * cot).sum().backward()
+    assert O.rel_err(y1.detach().cpu(), O.wavenet(x, sd, layers, False, impl="aten")) < TOL   # plain forward parity
     assert O.rel_err(y1.detach().cpu(), y0) < TOL
     worst = 0.0
     for k, p in net.named_parameters():
@@ -200,3 +203,21 @@ def test_errors_are_loud():
         blk(torch.randn(1, 9, 10, device=DEV))        # wrong channel count
     with pytest.raises(RuntimeError):
         M.CausalConv1d(4, 4, 9).to(DEV)(torch.randn(1, 4, 32, device=DEV))  # kernel_width 9 > WN_MAX_TAPS (8)
+
+
+def test_dense_degenerate_layout_does_not_alias_pool_buffers():
+    """k=1, C%8==0, L%128==0: the padded layout equals the dense one; outputs must still be private copies."""
+    import wavenet_speech_amd.functional as HF
+    torch.manual_seed(9)
+    w = (torch.randn(16, 16, 1) * 0.2).to(DEV).requires_grad_(True)
+    b = torch.randn(16).to(DEV).requires_grad_(True)
+    x = torch.randn(2, 16, 256)
+    cot = torch.randn(2, 16, 256)
+    y = HF.dilated_conv(x.to(DEV), w, b, 1, True)
+    y_before = y.detach().clone()
+    (y * cot.to(DEV)).sum().backward()          # backward recycles pooled buffers of the same shape
+    y2 = HF.dilated_conv(torch.randn(2, 16, 256, device=DEV), w, b, 1, True)
+    assert torch.equal(y.detach(), y_before)
+    ref = O.dilated_conv(x, w.detach().cpu(), b.detach().cpu(), 1, True)
+    assert O.rel_err(y.detach().cpu(), ref) < TOL
+    del y2

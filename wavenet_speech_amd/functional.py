@@ -38,6 +38,12 @@ def _require_device(t, what):
         raise RuntimeError("wavenet_speech_amd: %s must be float32, got %s" % (what, t.dtype))
 
 
+def _own(view):
+    """Fresh contiguous copy of a window of a pooled buffer.  `.contiguous()` is NOT enough: when halo == 0, L is a
+    multiple of 128 and C a multiple of 8 the padded layout is already dense and it would return the alias."""
+    return view.clone(memory_format=torch.contiguous_format)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -149,7 +155,8 @@ class _ResidualStackFn(torch.autograd.Function):
             cur = r
         ctx.specs, ctx.saved, ctx.layout, ctx.batch = specs, saved, layout, B
         ctx.param_shapes = [tuple(t.shape) for t in flat]
-        return window(S, ms, layout)
+        # hand autograd a tensor of its own: views of internal buffers must never escape a custom Function
+        return window(S, ms, layout).clone(memory_format=torch.contiguous_format)
 
     @staticmethod
     @once_differentiable
@@ -209,7 +216,7 @@ class _ResidualBlockFn(torch.autograd.Function):
             ctx.saved = (xin, ta, sg, z, packed, shape)
         ctx.spec, ctx.layout, ctx.batch = spec, layout, B
         ctx.param_shapes = [tuple(t.shape) for t in params]
-        return r.view().contiguous(), s.view().contiguous()
+        return _own(r.view()), _own(s.view())
 
     @staticmethod
     @once_differentiable
@@ -223,7 +230,7 @@ class _ResidualBlockFn(torch.autograd.Function):
         load_series(ds.t, d_s, layout)
         dx, grads = _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, ds, ctx.needs_input_grad[0], layout, B, dev)
         grads = [g.view(shp) for g, shp in zip(grads, ctx.param_shapes)]
-        dx0 = dx.view().contiguous() if dx is not None else None
+        dx0 = _own(dx.view()) if dx is not None else None
         ctx.saved = None
         return (dx0, None) + tuple(grads)
 
@@ -263,7 +270,7 @@ class _DilatedConvFn(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.saved = (xin, packed, shape)
         ctx.layout, ctx.dims, ctx.has_bias = layout, (B, Ci, Co, k), bias is not None
-        return y.view().contiguous()
+        return _own(y.view())
 
     @staticmethod
     @once_differentiable
@@ -280,7 +287,7 @@ class _DilatedConvFn(torch.autograd.Function):
             dx = Lease(B, Ci, layout, dev)
             _lib.check(lib.wn_conv_backward_data(ctypes.byref(shape), _p(packed), _p(dy), _p(dx), _stream()),
                        "wn_conv_backward_data")
-            dx0 = dx.view().contiguous()
+            dx0 = _own(dx.view())
         dw = torch.empty(Co, Ci, k, dtype=torch.float32, device=dev)
         db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws_bytes = lib.wn_conv_wgrad_workspace_bytes(ctypes.byref(shape))

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .block import ResidualBlock, run_stack
+from .pointwise import run_sequential
 
 
 class WaveNetClassifier(nn.Module):
@@ -40,7 +41,7 @@ class WaveNetClassifier(nn.Module):
         out = self.mean_pool(seq)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
                               [self.input_skip_bottleneck] + list(self.bottlenecks))
-        logit_seq = self.output_block(skips_sum)
+        logit_seq = run_sequential(self.output_block, skips_sum)
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)

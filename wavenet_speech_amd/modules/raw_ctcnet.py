@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .block import ResidualBlock, run_stack
+from .pointwise import run_sequential
 
 
 class RawCTCNet(nn.Module):
@@ -54,13 +55,13 @@ class RawCTCNet(nn.Module):
                     noisy_zero(p)
 
     def forward(self, seq):
-        out = self.feature_layer(seq)
+        out = run_sequential(self.feature_layer, seq)
         if self.positions:
             steps = torch.arange(0., out.size(2), device=seq.device).view(1, 1, -1)
-            out = out + self.positions_conv1x1(steps)
+            out = out + run_sequential(self.positions_conv1x1, steps)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
                               [self.input_skip_bottleneck] + list(self.bottlenecks))
-        logit_seq = self.output_block(skips_sum)
+        logit_seq = run_sequential(self.output_block, skips_sum)
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)

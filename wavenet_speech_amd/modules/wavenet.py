@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 from .block import ResidualBlock, run_stack
 from .conv_ops import CausalConv1d
+from .pointwise import run_sequential
 
 
 def _init_weights_and_zero_bias(params):
@@ -44,7 +45,7 @@ class WaveNet(nn.Module):
     def forward(self, signal):
         out = self.entry_conv1d(signal)
         skips_sum = run_stack(out, self.convolutions, self.bottlenecks)
-        output_seq = self.output_stack(skips_sum)
+        output_seq = run_sequential(self.output_stack, skips_sum)
         if not self.softmax:
             return output_seq
         return F.softmax(output_seq, dim=1)  # the reference's reshape_in/softmax/reshape_out == softmax over channels
