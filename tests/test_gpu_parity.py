@@ -221,3 +221,24 @@ def test_dense_degenerate_layout_does_not_alias_pool_buffers():
     ref = O.dilated_conv(x, w.detach().cpu(), b.detach().cpu(), 1, True)
     assert O.rel_err(y.detach().cpu(), ref) < TOL
     del y2
+
+
+def test_gate_activation_accuracy():
+    """the gate epilogue's exp2/rcp based tanh and sigmoid: absolute error vs torch (fp64) over a wide input sweep"""
+    M = _mods()
+    c = 32
+    blk = M.ResidualBlock(c, c, 2, 1).to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.zero_()
+        # a = x (identity on tap 1), g = x  -> ta = tanh(x), sg = sigmoid(x); read them back through z = ta*sg via skip = I z
+        blk.conv_tanh.conv1d.weight[:, :, 1] = torch.eye(c)
+        blk.conv_sigmoid.conv1d.weight[:, :, 1] = torch.eye(c)
+        blk.conv1x1_skip.weight[:, :, 0] = torch.eye(c)
+    x = torch.cat([torch.linspace(-30, 30, 4096), torch.linspace(-0.3, 0.3, 4096), torch.tensor([0.0, 1e-6, -1e-6, 88.0, -88.0, 0.124999, 0.125001])])
+    x = x[: (x.numel() // c) * c].view(1, c, -1).contiguous()
+    with torch.no_grad():
+        _, s = blk(x.to(DEV))
+    ref = (torch.tanh(x.double()) * torch.sigmoid(x.double()))
+    err = float((s.cpu().double() - ref).abs().max())
+    assert err < 3e-7, err

@@ -1,0 +1,81 @@
+// Micro-benchmark (MI355X): cycles per v_mfma_f32_32x32x2_f32 for (1) a bare loop with 16 independent 32x32
+// accumulators, (2) the same with 8 global_load_dwordx4 per 64 MFMAs feeding later MFMAs (the series-GEMM pattern),
+// (3) as (2) but loads consumed one block later without sched_barrier.   hipcc --offload-arch=gfx950 -O3 -o mfma_rate mfma_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k(const float* __restrict__ w, const float* __restrict__ x, float* out,
+                                        unsigned long long* stamps, int nkb, int ld) {
+    const int lane = threadIdx.x;
+    f32x16 acc[4][4];
+    for (int m = 0; m < 4; ++m) for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    const float* wp = w + lane * 4;
+    const float* bp = x + (size_t)(blockIdx.x % 64) * 128 + (size_t)(4 * (lane >> 5)) * ld + 4 * (lane & 31);
+    f32x4 A[2][4], B[2][4];
+    for (int m = 0; m < 4; ++m) { A[0][m] = *(const f32x4*)(wp + m * 256); A[1][m] = A[0][m]; }
+    for (int q = 0; q < 4; ++q) { B[0][q] = *(const f32x4*)(bp + (size_t)q * ld); B[1][q] = B[0][q]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < nkb; g += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (MODE >= 1) {
+                wp += 1024; bp += 8 * (size_t)ld;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) A[(j + 1) & 1][m] = *(const f32x4*)(wp + m * 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) B[(j + 1) & 1][q] = *(const f32x4*)(bp + (size_t)q * ld);
+            }
+            if (MODE != 3) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j & 1][m][q], B[j & 1][q][t], acc[m][t], 0, 0, 0);
+            if (MODE != 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int m = 0; m < 4; ++m) for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[m][t][r];
+    out[blockIdx.x * 64 + lane] = s;
+    if (lane == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = t1; }
+}
+
+template <int MODE>
+void run(const char* name, float* w, float* x, float* out, unsigned long long* st, int nkb, int ld, int grid) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(2 * grid); hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> c(grid); for (int i = 0; i < grid; ++i) c[i] = double(h[2 * i + 1] - h[2 * i]);
+    std::sort(c.begin(), c.end());
+    const double nm = double(nkb) * 64;
+    printf("%-44s grid %5d  %.3f ms  cycles/MFMA median %.2f (p10 %.2f p90 %.2f)  -> %.1f TFLOP/s\n", name, grid, ms,
+           c[grid / 2] / nm, c[grid / 10] / nm, c[grid * 9 / 10] / nm, double(grid) * nm * 4096.0 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const int ld = 17024, rows = 2048, nkb = 128;
+    float *w, *x, *out; unsigned long long* st;
+    hipMalloc(&w, (size_t)(nkb + 2) * 1024 * 4); hipMalloc(&x, (size_t)rows * ld * 4); hipMalloc(&out, 8192 * 64 * 4); hipMalloc(&st, 8192 * 16);
+    hipMemset(w, 0, (size_t)(nkb + 2) * 1024 * 4); hipMemset(x, 0, (size_t)rows * ld * 4);
+    for (int grid : {1024, 4096}) {
+        run<0>("bare MFMA loop (operands in registers)", w, x, out, st, nkb, ld, grid);
+        run<1>("+ 8 dwordx4 loads / 64 MFMAs, sched_barrier", w, x, out, st, nkb, ld, grid);
+        run<3>("+ 8 dwordx4 loads / 64 MFMAs, free schedule", w, x, out, st, nkb, ld, grid);
+    }
+    return 0;
+}

@@ -16,6 +16,10 @@
 
 using namespace wn;
 
+#ifdef WN_STAMPS
+namespace wn { extern int g_debug_kc; }   // diagnostic build: which kernel class the next launch belongs to
+#endif
+
 namespace {
 
 thread_local std::string g_hip_err;
@@ -42,12 +46,12 @@ inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 // ------------------------------------------------------------------------------------------
 enum KernelClass {
     KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE,
-    KC_CONV_FWD, KC_CONV_BWD_DATA, KC_COUNT
+    KC_CONV_FWD, KC_CONV_BWD_DATA, KC_SKIP_GEMM, KC_COUNT
 };
 const char* const kKernelNames[KC_COUNT] = {
-    "pack_kernel", "series_gemm_kernel<gate>", "series_gemm_kernel<res+skip>", "series_gemm_kernel<dz,dgate>",
+    "pack_kernel", "series_gemm_kernel<gate>", "series_gemm_kernel<res>", "series_gemm_kernel<dz,dgate>",
     "series_gemm_kernel<dx>", "wgrad_kernel", "wgrad_reduce_kernel", "series_gemm_kernel<conv_fwd>",
-    "series_gemm_kernel<conv_bwd_data>"};
+    "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skip+=>"};
 
 struct ProfRec { int kc; hipEvent_t e0, e1; double flops; };
 struct Prof {
@@ -65,6 +69,9 @@ struct ProfScope {
     ProfRec rec{};
     hipStream_t st;
     ProfScope(int kc, double flops, hipStream_t s) : st(s) {
+#ifdef WN_STAMPS
+        wn::g_debug_kc = kc;
+#endif
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (!g_prof.on) return;
         auto get = [&]() {
@@ -422,17 +429,25 @@ int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x
         ProfScope prof(KC_GATE_GEMM, 2.0 * (2.0 * Co) * (double)(k * Ci) * BL, st);
         WN_HIP(launch_gemm(g.MT, EPI_GATE, a, st), "series_gemm<gate>");
     }
-    {   // r = W_res z + W_proj x + b ;  skip (+)= W_skip z + b
+    // r = W_res z + W_proj x + b   and   skip (+)= W_skip z + b : two launches of the same packed GEMM, so that the
+    // accumulating skip slabs get their own lean instantiation (EPI_ACCUM) and waves of equal length run together
+    {
         const GemmPlan& g = bp.fb;
-        const int first = r_out ? 0 : bp.fb_first_skip_slab;
-        fill_gemm_common(a, g, packed, bp.off_fb, first, g.nslab - first, s->batch, s->length, s->ld, s->halo);
+        const double fl_r = 2.0 * Co * (double)(Co + Ci) * BL, fl_s = 2.0 * Ms * (double)Co * BL;
+        if (r_out) {
+            fill_gemm_common(a, g, packed, bp.off_fb, 0, bp.fb_first_skip_slab, s->batch, s->length, s->ld, s->halo);
+            set_seg(a, 0, z, Co, 0, g.seg_nkb[0]);
+            set_seg(a, 1, x, Ci, 0, g.seg_nkb[1]);
+            a.dst[0].base = r_out; a.dst[0].cp = cp8(Co); a.dst[0].rows = Co; a.dst[0].accumulate = 0;
+            ProfScope prof(KC_OUT_GEMM, fl_r, st);
+            WN_HIP(launch_gemm(g.MT, EPI_LINEAR, a, st), "series_gemm<res>");
+        }
+        fill_gemm_common(a, g, packed, bp.off_fb, bp.fb_first_skip_slab, g.nslab - bp.fb_first_skip_slab, s->batch,
+                         s->length, s->ld, s->halo);
         set_seg(a, 0, z, Co, 0, g.seg_nkb[0]);
-        set_seg(a, 1, x, Ci, 0, g.seg_nkb[1]);
-        a.dst[0].base = r_out; a.dst[0].cp = cp8(Co); a.dst[0].rows = Co; a.dst[0].accumulate = 0;
         a.dst[1].base = skip; a.dst[1].cp = cp8(Ms); a.dst[1].rows = Ms; a.dst[1].accumulate = skip_accumulate ? 1 : 0;
-        const double fl = (r_out ? 2.0 * Co * (double)(Co + Ci) * BL : 0.0) + 2.0 * Ms * (double)Co * BL;
-        ProfScope prof(KC_OUT_GEMM, fl, st);
-        WN_HIP(launch_gemm(g.MT, EPI_LINEAR, a, st), "series_gemm<res+skip>");
+        ProfScope prof(KC_SKIP_GEMM, fl_s, st);
+        WN_HIP(launch_gemm(g.MT, skip_accumulate ? EPI_ACCUM : EPI_LINEAR, a, st), "series_gemm<skip>");
     }
     return WN_OK;
 }

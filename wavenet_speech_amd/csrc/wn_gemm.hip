@@ -27,7 +27,21 @@ namespace wn {
 
 __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / tanh from one v_exp_f32 + one v_rcp_f32 each (both 1 ulp).  Absolute error <= ~2e-7 (measured against
+// torch in tests/test_gpu_parity.py::test_gate_activation_accuracy); the ocml tanhf/expf pair cost 24 us of VALU per
+// 128x128 tile, i.e. 15 % of the gate GEMM's wave time (tools/block_stamps.py).
+__device__ __forceinline__ float sigmoid_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * x);   // exp(-x); inf for x << 0 -> result 0
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * ax);  // exp(-2|x|) in (0, 1]
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    const float x2 = x * x;                                                // |x| < 0.125: odd Taylor series, rel. err < 1e-8
+    const float small = ax * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * -0.0539682540f)));
+    return __builtin_copysignf(ax < 0.125f ? small : big, x);
+}
 
 // B operand of one k-step: NT consecutive time steps of one channel row (one 16- or 8-byte load per lane)
 template <int NT> struct BVec;
@@ -63,15 +77,47 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     const GemmSlab sl = a.slab[slab_i];
     const int ld = a.ld;
 
-    // ---- accumulators, initialised with the bias of their row --------------------------------
+    // ---- accumulators ---------------------------------------------------------------------------
+    // EPI_ACCUM (the stack's running skips_sum += ...): the destination tile is loaded straight into the accumulators
+    // here -- all 16*MT loads of a lane in flight at once, no VALU in between -- and the bias is added at store time,
+    // so the epilogue is a plain store.  (A read-modify-write epilogue cost 45 us of a 112 us wave: 64 dependent
+    // load->add->store rounds; tools/block_stamps.py.)  Every other epilogue starts from the row's bias.
     f32x16 acc[MT][NT];
+    if constexpr (EPI == EPI_ACCUM) {
+        const GemmDst d0 = a.dst[sl.dst];
+        const float* pre = d0.base + (long)b * d0.cp * ld + a.halo + t0 + NT * n;
+        constexpr int RB = 8, BPT = 16 / RB, NBATCH = MT * BPT;   // 8-row batches, one batch ahead
+        breg_t stage[2][RB];
+        auto fetch = [&](int bi, breg_t (&dst)[RB]) {
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+            for (int i = 0; i < RB; ++i) {
+                int row = sl.row0 + 32 * m + rowof(r0 + i, h);
+                row = row < d0.rows ? row : d0.rows - 1;   // rows past the end are never stored: clamp, don't branch
+                dst[i] = *reinterpret_cast<const breg_t*>(pre + (unsigned)(row * ld));
+            }
+        };
+        fetch(0, stage[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r, h)] : 0.0f;
+        for (int bi = 0; bi < NBATCH; ++bi) {
+            if (bi + 1 < NBATCH) fetch(bi + 1, stage[(bi + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t][r] = bv;
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t][r0 + i] = stage[bi & 1][i][t];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r, h)] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[m][t][r] = bv;
+            }
         }
     }
 
@@ -164,19 +210,38 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
         return v;
     };
 
-    if constexpr (EPI == EPI_LINEAR) {
+    if constexpr (EPI == EPI_LINEAR || EPI == EPI_ACCUM) {
         const GemmDst d = a.dst[sl.dst];
+        float* dbase = d.base;
+        int he = h;
+        if constexpr (EPI == EPI_ACCUM) {
+            // opaque to the optimiser: otherwise the row indices / store addresses are CSE'd with the preload's and
+            // kept alive (= spilled) across the whole K loop; they are cheaper to recompute
+            asm volatile("" : "+s"(dbase));
+            asm volatile("" : "+v"(he));
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            f32x4 bv[4];   // the 16 rows of a lane are 4 groups of 4 consecutive rows: (r&3) + 8*(r>>2) + 4*h
+            if constexpr (EPI == EPI_ACCUM) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + sl.boff + 32 * m + 8 * g + 4 * he) : zero;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = sl.row0 + 32 * m + rowof(r, h);
+                const int row = sl.row0 + 32 * m + rowof(r, he);
                 if (row < d.rows) {
-                    float* p = d.base + ((long)b * d.cp + row) * ld + colbase;
+                    float* p = dbase + ((long)b * d.cp + row) * ld + colbase;
                     breg_t v;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r];
-                    if (d.accumulate) v += *reinterpret_cast<const breg_t*>(p);
+                    if constexpr (EPI == EPI_ACCUM) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) v[t] += bv[r >> 2][r & 3];
+                    }
                     *reinterpret_cast<breg_t*>(p) = clip(v);
                 }
             }
@@ -193,7 +258,7 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
                     breg_t vt, vs, vz;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float tt = tanhf(acc[2 * i][t][r]);
+                        const float tt = tanh_f(acc[2 * i][t][r]);
                         const float ss = sigmoid_f(acc[2 * i + 1][t][r]);
                         vt[t] = tt;
                         vs[t] = ss;
@@ -210,21 +275,42 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {  // EPI_DGATE: acc = dz ; da = dz*sg*(1-ta^2), dg = dz*ta*sg*(1-sg)
+        // ta/sg come from HBM: issue a whole batch of rows (up to 32 x 16 B per lane in flight) before using any of
+        // them -- row-by-row load->use chains cost 55 us of a 186 us wave (tools/block_stamps.py).
+        constexpr int RB = (MT == 4) ? 8 : 4;   // rows per batch: 2 x RB x 16 B per lane in flight, one batch ahead
+        constexpr int BPT = 16 / RB;            // batches per 32-row tile
+        constexpr int NBATCH = MT * BPT;
+        breg_t vt[2][RB], vs[2][RB];
+        auto fetch = [&](int bi, breg_t (&ft)[RB], breg_t (&fs)[RB]) {
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+            for (int i = 0; i < RB; ++i) {
+                int ch = sl.row0 + 32 * m + rowof(r0 + i, h);
+                ch = ch < a.gate_rows ? ch : a.gate_rows - 1;   // clamp (never stored), no branch
+                const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
+                ft[i] = *reinterpret_cast<const breg_t*>(a.ta + o);
+                fs[i] = *reinterpret_cast<const breg_t*>(a.sg + o);
+            }
+        };
+        fetch(0, vt[0], vs[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+        for (int bi = 0; bi < NBATCH; ++bi) {
+            if (bi + 1 < NBATCH) fetch(bi + 1, vt[(bi + 1) & 1], vs[(bi + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int r = r0 + i;
                 const int ch = sl.row0 + 32 * m + rowof(r, h);
                 if (ch < a.gate_rows) {
                     const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
-                    const breg_t vt = *reinterpret_cast<const breg_t*>(a.ta + o);
-                    const breg_t vs = *reinterpret_cast<const breg_t*>(a.sg + o);
+                    const breg_t ta_ = vt[bi & 1][i], sg_ = vs[bi & 1][i];
                     breg_t va, vg;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float dz = acc[m][t][r];
-                        va[t] = dz * vs[t] * (1.0f - vt[t] * vt[t]);
-                        vg[t] = dz * vt[t] * vs[t] * (1.0f - vs[t]);
+                        va[t] = dz * sg_[t] * (1.0f - ta_[t] * ta_[t]);
+                        vg[t] = dz * ta_[t] * sg_[t] * (1.0f - sg_[t]);
                     }
                     *reinterpret_cast<breg_t*>(a.da + o) = clip(va);
                     *reinterpret_cast<breg_t*>(a.dg + o) = clip(vg);
@@ -237,21 +323,25 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 
 #ifdef WN_STAMPS
 static unsigned long long* g_stamp_buf = nullptr;
+static int g_stamp_kc = -1;          // only launches of this kernel class write stamps (-1: all)
+int g_debug_kc = -1;                 // set by the API layer before each launch
 extern "C" void wn_debug_set_stamp_buffer(void* p) { g_stamp_buf = (unsigned long long*)p; }
+extern "C" void wn_debug_set_stamp_class(int kc) { g_stamp_kc = kc; }
 extern "C" unsigned wn_debug_last_grid = 0;
 #endif
 
 template <int MT, int NT, int EPI, int PFB, int WPS>
 static hipError_t launch_one(GemmArgs a, hipStream_t st) {
 #ifdef WN_STAMPS
-    a.stamps = g_stamp_buf;
+    const bool stamp_this = g_stamp_buf && (g_stamp_kc < 0 || g_stamp_kc == g_debug_kc);
+    a.stamps = stamp_this ? g_stamp_buf : nullptr;
 #endif
     a.tiles_per_row = (a.L + 32 * NT - 1) / (32 * NT);
     a.ncol = a.B * a.tiles_per_row;
     const int ncol8 = (a.ncol + 7) / 8 * 8;
     const unsigned grid = (unsigned)(a.nslab * ncol8);
 #ifdef WN_STAMPS
-    wn_debug_last_grid = grid;
+    if (stamp_this) wn_debug_last_grid = grid;
 #endif
     hipLaunchKernelGGL((series_gemm_kernel<MT, NT, EPI, PFB, WPS>), dim3(grid), dim3(64), 0, st, a);
     return hipGetLastError();
@@ -290,6 +380,7 @@ hipError_t launch_gemm(int MT, int epi, const GemmArgs& a, hipStream_t st) {
         case EPI_LINEAR: return launch_epi<EPI_LINEAR>(MT, a, st);
         case EPI_GATE: return launch_epi<EPI_GATE>(MT, a, st);
         case EPI_DGATE: return launch_epi<EPI_DGATE>(MT, a, st);
+        case EPI_ACCUM: return launch_epi<EPI_ACCUM>(MT, a, st);
     }
     return hipErrorInvalidValue;
 }

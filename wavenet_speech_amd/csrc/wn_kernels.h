@@ -69,7 +69,7 @@ struct GemmArgs {
     unsigned long long* stamps;  // diagnostic build (-DWN_STAMPS) only: 8 words per workgroup
 };
 
-enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_DGATE = 2 };
+enum { EPI_LINEAR = 0, EPI_GATE = 1, EPI_DGATE = 2, EPI_ACCUM = 3 };  // ACCUM: dst += result (+ bias)
 
 // ---------------------------------------------------------------------------------------------
 // weight packing: logical matrix element (slab, tile m, row i, seg, c) -> source tensors

@@ -65,17 +65,35 @@ def fold_bottleneck(block, bottleneck):
     """bottleneck(conv1x1_skip(z)) = (Wb Wk) z + (Wb bk + bb): two tiny [D,C]x[C,C] torch products per step
     (autograd carries the chain rule back to both parameters), so the stack kernel accumulates skips_sum
     directly and skip_out never touches HBM."""
-    wb = bottleneck.weight[:, :, 0]
-    wk = block.conv1x1_skip.weight[:, :, 0]
+    wb = bottleneck.weight.squeeze(2)
+    wk = block.conv1x1_skip.weight.squeeze(2)
     return wb @ wk, wb @ block.conv1x1_skip.bias + bottleneck.bias
+
+
+def fold_bottlenecks(blocks, bottlenecks):
+    """fold_bottleneck for a whole stack.  When every block has the same width (all reference configs) the folds are
+    batched into one bmm / baddbmm: rocBLAS spends ~63 us on each separate 256^3 product (a single workgroup), i.e.
+    5.7 ms per step at 30 blocks, against ~0.1 ms batched.  stack/unbind keep the autograd graph free of per-block
+    fill/copy kernels."""
+    shapes = set((tuple(b.weight.shape), tuple(k.conv1x1_skip.weight.shape)) for k, b in zip(blocks, bottlenecks))
+    if len(shapes) != 1:
+        folded = [fold_bottleneck(k, b) for k, b in zip(blocks, bottlenecks)]
+        return [w for w, _ in folded], [b for _, b in folded]
+    wb = torch.stack([b.weight.squeeze(2) for b in bottlenecks])                   # [n, D, C]
+    wk = torch.stack([k.conv1x1_skip.weight.squeeze(2) for k in blocks])           # [n, C, C]
+    bk = torch.stack([k.conv1x1_skip.bias for k in blocks]).unsqueeze(2)           # [n, C, 1]
+    bb = torch.stack([b.bias for b in bottlenecks]).unsqueeze(2)                   # [n, D, 1]
+    wf = torch.bmm(wb, wk)
+    bf = torch.baddbmm(bb, wb, bk).squeeze(2)
+    return list(wf.unbind(0)), list(bf.unbind(0))
 
 
 def run_stack(out, blocks, bottlenecks):
     """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path"""
     specs, flat = [], []
     out_dim = bottlenecks[0].out_channels
-    for blk, bott in zip(blocks, bottlenecks):
-        w, b = fold_bottleneck(blk, bott)
+    wfs, bfs = fold_bottlenecks(list(blocks), list(bottlenecks))
+    for blk, w, b in zip(blocks, wfs, bfs):
         specs.append(blk.spec(out_dim))
         flat.extend(blk.hip_params(w, b))
     return HF.residual_stack(out, specs, flat)
