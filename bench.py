@@ -115,12 +115,19 @@ def cpu_baseline(channels, cycles, seq_len, budget_s=12.0):
 
 def main():
     args = parse()
+    # RCCL / MIOpen print banners on stdout; the contract is ONE JSON line there.  Send fd 1 to stderr for the run
+    # and restore it only to print the result.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    distributed = world > 1
+    # under torch.distributed.run (RANK set) the RCCL group is always created, even for one rank, so the same
+    # code path (init, barrier, flat-gradient all-reduce, MAX over ranks) runs at N=1 and N=8
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -237,10 +244,13 @@ def main():
         del net, opt, sync, x, cot
         torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(C, args.cycles, args.cpu_seq_len)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if distributed:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

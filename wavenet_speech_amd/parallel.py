@@ -59,13 +59,13 @@ class FlatGradAllReduce(object):
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-        w = self.world()
-        if w == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return None
+        w = self.world()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return work
-        if self.average:
+        if self.average and w > 1:
             self.flat.div_(w)
         return None
 
