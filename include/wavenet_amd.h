@@ -109,11 +109,29 @@ int wn_block_pack(const wn_block_shape* s, const wn_block_params* p, void* packe
  *   r    = W_res z + b_res + W_proj x + b_proj                       -> r_out (may be NULL: not needed)
  *   skip = W_skip z + b_skip                                         -> skip  (skip_accumulate=0)
  *   skip += W_skip z + b_skip   (the stack's running skips_sum)       -> skip  (skip_accumulate=1)
+ *   skip == NULL: the skip product is left to wn_skipsum_forward (below)
  *   ta, sg, z are saved for the backward pass (each may be NULL for inference, all-or-none).
  * x: [B][Ci8][ld]; r_out, ta, sg, z: [B][Co8][ld]; skip: [B][Ms8][ld]. */
 int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x,
                      float* r_out, float* skip, int skip_accumulate,
                      float* ta, float* sg, float* z, wn_stream_t stream);
+
+/* ---- skips_sum of a whole stack as ONE long-K product (training, where every block's z is kept anyway) ----
+ *   skip (+)= sum_l W_skip_l z_l + bias_total        == the sum over l of modules/wavenet.py:100
+ * Call wn_block_forward with skip == NULL for each block (it then skips the per-block accumulation) and this once
+ * per group of <= WN_MAX_STACK_GROUP blocks: K = sum_l C_l amortises the per-wave costs that dominate the per-block
+ * K = C_l product and removes 2 HBM passes over skips_sum per block.
+ * w_skip / z are HOST arrays of nblocks DEVICE pointers ([Ms][C_l] matrices and [B][C_l 8][ld] series). */
+#define WN_MAX_STACK_GROUP 32
+typedef struct wn_skipsum_shape {
+    int batch, length, skip_rows, nblocks, ld, halo;
+    int channels[WN_MAX_STACK_GROUP]; /* C_l */
+} wn_skipsum_shape;
+size_t wn_skipsum_packed_bytes(const wn_skipsum_shape* s);
+int wn_skipsum_pack(const wn_skipsum_shape* s, const float* const* w_skip, const float* bias_total /* [Ms] or NULL */,
+                    void* packed, wn_stream_t stream);
+int wn_skipsum_forward(const wn_skipsum_shape* s, const void* packed, const float* const* z, float* skip,
+                       int accumulate, wn_stream_t stream);
 
 /* ---- backward (data): what autograd computes through modules/block.py:54-82 ----------------
  *   dz = W_res^T dr + W_skip^T dskip ;  da = dz*sg*(1-ta^2) ;  dg = dz*ta*sg*(1-sg)     -> da, dg

@@ -30,6 +30,15 @@ class BlockParams(Structure):
                                          "w_skip", "b_skip", "w_proj", "b_proj")]
 
 
+MAX_STACK_GROUP = 32
+
+
+class SkipSumShape(Structure):
+    """wn_skipsum_shape"""
+    _fields_ = [("batch", c_int), ("length", c_int), ("skip_rows", c_int), ("nblocks", c_int), ("ld", c_int),
+                ("halo", c_int), ("channels", c_int * MAX_STACK_GROUP)]
+
+
 class ConvShape(Structure):
     """wn_conv_shape"""
     _fields_ = [("batch", c_int), ("length", c_int), ("in_channels", c_int), ("out_channels", c_int),
@@ -50,6 +59,9 @@ SIGNATURES = {
     "wn_block_pack": (c_int, [POINTER(BlockShape), POINTER(BlockParams), c_void_p, c_void_p]),
     "wn_block_forward": (c_int, [POINTER(BlockShape), c_void_p, c_float_p, c_float_p, c_float_p, c_int,
                                  c_float_p, c_float_p, c_float_p, c_void_p]),
+    "wn_skipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape)]),
+    "wn_skipsum_pack": (c_int, [POINTER(SkipSumShape), POINTER(c_void_p), c_float_p, c_void_p, c_void_p]),
+    "wn_skipsum_forward": (c_int, [POINTER(SkipSumShape), c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
     "wn_block_backward_data": (c_int, [POINTER(BlockShape), c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                        c_float_p, c_float_p, c_float_p, c_void_p]),
     "wn_block_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape)]),

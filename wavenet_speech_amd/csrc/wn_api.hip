@@ -51,7 +51,7 @@ enum KernelClass {
 const char* const kKernelNames[KC_COUNT] = {
     "pack_kernel", "series_gemm_kernel<gate>", "series_gemm_kernel<res>", "series_gemm_kernel<dz,dgate>",
     "series_gemm_kernel<dx>", "wgrad_kernel", "wgrad_reduce_kernel", "series_gemm_kernel<conv_fwd>",
-    "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skip+=>"};
+    "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skips_sum>"};
 
 struct ProfRec { int kc; hipEvent_t e0, e1; double flops; };
 struct Prof {
@@ -414,7 +414,7 @@ int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x
     int off[WN_MAX_TAPS];
     int rc = check_block(s, off);
     if (rc != WN_OK) return rc;
-    if (!packed || !x || !skip || !z) return WN_ERR_NULL;
+    if (!packed || !x || !z) return WN_ERR_NULL;
     if ((ta == nullptr) != (sg == nullptr)) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const BlockPlan bp = plan_block(s);
@@ -442,12 +442,14 @@ int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x
             ProfScope prof(KC_OUT_GEMM, fl_r, st);
             WN_HIP(launch_gemm(g.MT, EPI_LINEAR, a, st), "series_gemm<res>");
         }
-        fill_gemm_common(a, g, packed, bp.off_fb, bp.fb_first_skip_slab, g.nslab - bp.fb_first_skip_slab, s->batch,
-                         s->length, s->ld, s->halo);
-        set_seg(a, 0, z, Co, 0, g.seg_nkb[0]);
-        a.dst[1].base = skip; a.dst[1].cp = cp8(Ms); a.dst[1].rows = Ms; a.dst[1].accumulate = skip_accumulate ? 1 : 0;
-        ProfScope prof(KC_SKIP_GEMM, fl_s, st);
-        WN_HIP(launch_gemm(g.MT, skip_accumulate ? EPI_ACCUM : EPI_LINEAR, a, st), "series_gemm<skip>");
+        if (skip) {
+            fill_gemm_common(a, g, packed, bp.off_fb, bp.fb_first_skip_slab, g.nslab - bp.fb_first_skip_slab, s->batch,
+                             s->length, s->ld, s->halo);
+            set_seg(a, 0, z, Co, 0, g.seg_nkb[0]);
+            a.dst[1].base = skip; a.dst[1].cp = cp8(Ms); a.dst[1].rows = Ms; a.dst[1].accumulate = skip_accumulate ? 1 : 0;
+            ProfScope prof(KC_SKIP_GEMM, fl_s, st);
+            WN_HIP(launch_gemm(g.MT, skip_accumulate ? EPI_ACCUM : EPI_LINEAR, a, st), "series_gemm<skip>");
+        }
     }
     return WN_OK;
 }
@@ -491,6 +493,75 @@ int wn_block_backward_data(const wn_block_shape* s, const void* packed, const fl
         ProfScope prof(KC_DX_GEMM, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
         WN_HIP(launch_gemm(g.MT, EPI_LINEAR, a, st), "series_gemm<dx>");
     }
+    return WN_OK;
+}
+
+// ---- skips_sum of a whole stack ---------------------------------------------------------------------
+namespace {
+int check_skipsum(const wn_skipsum_shape* s) {
+    if (!s) return WN_ERR_NULL;
+    if (s->nblocks < 1 || s->skip_rows <= 0) return WN_ERR_BAD_SHAPE;
+    if (s->nblocks > WN_MAX_STACK_GROUP || s->skip_rows > WN_MAX_CHANNELS) return WN_ERR_UNSUPPORTED;
+    for (int l = 0; l < s->nblocks; ++l) {
+        if (s->channels[l] <= 0) return WN_ERR_BAD_SHAPE;
+        if (s->channels[l] > WN_MAX_CHANNELS) return WN_ERR_UNSUPPORTED;
+    }
+    return check_layout(s->batch, s->length, s->ld, s->halo, 0);
+}
+GemmPlan plan_skipsum(const wn_skipsum_shape* s) {
+    GemmPlan g;
+    const int t = tiles32(s->skip_rows);
+    g.MT = pick_mt(t);
+    g.nseg = s->nblocks;
+    for (int l = 0; l < s->nblocks; ++l) g.seg_nkb[l] = cp8(s->channels[l]) / 8;
+    for (int i = 0; i < cdiv(t, g.MT); ++i) g.add_slab(s->nblocks, i * g.MT * 32, 0);
+    return g;
+}
+}  // namespace
+
+size_t wn_skipsum_packed_bytes(const wn_skipsum_shape* s) {
+    if (check_skipsum(s) != WN_OK) return 0;
+    return plan_skipsum(s).bytes();
+}
+
+int wn_skipsum_pack(const wn_skipsum_shape* s, const float* const* w_skip, const float* bias_total, void* packed,
+                    wn_stream_t stream) {
+    int rc = check_skipsum(s);
+    if (rc != WN_OK) return rc;
+    if (!w_skip || !packed) return WN_ERR_NULL;
+    for (int l = 0; l < s->nblocks; ++l) if (!w_skip[l]) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const GemmPlan g = plan_skipsum(s);
+    ProfScope prof(KC_PACK, 0.0, st);
+    PackArgs a;
+    fill_pack_common(a, g, packed, 0);
+    for (int l = 0; l < s->nblocks; ++l) a.set[0].seg[l] = mk_src(w_skip[l], s->skip_rows, s->channels[l], s->channels[l], 1);
+    a.set[0].bias0 = bias_total; a.set[0].bias_rows = s->skip_rows;
+    for (int sl = 0; sl < g.nslab; ++sl)
+        for (int m = 0; m < g.MT; ++m) {
+            const int row0 = g.slab_row0[sl] + 32 * m;
+            a.tile[sl * g.MT + m].set = 0;
+            a.tile[sl * g.MT + m].row0 = row0 < s->skip_rows ? row0 : -1;
+        }
+    WN_HIP(launch_pack(a, st), "pack(skipsum)");
+    return WN_OK;
+}
+
+int wn_skipsum_forward(const wn_skipsum_shape* s, const void* packed, const float* const* z, float* skip, int accumulate,
+                       wn_stream_t stream) {
+    int rc = check_skipsum(s);
+    if (rc != WN_OK) return rc;
+    if (!packed || !z || !skip) return WN_ERR_NULL;
+    for (int l = 0; l < s->nblocks; ++l) if (!z[l]) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const GemmPlan g = plan_skipsum(s);
+    GemmArgs a;
+    fill_gemm_common(a, g, packed, 0, 0, g.nslab, s->batch, s->length, s->ld, s->halo);
+    double ksum = 0;
+    for (int l = 0; l < s->nblocks; ++l) { set_seg(a, l, z[l], s->channels[l], 0, g.seg_nkb[l]); ksum += s->channels[l]; }
+    a.dst[0].base = skip; a.dst[0].cp = cp8(s->skip_rows); a.dst[0].rows = s->skip_rows; a.dst[0].accumulate = accumulate ? 1 : 0;
+    ProfScope prof(KC_SKIP_GEMM, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
+    WN_HIP(launch_gemm(g.MT, accumulate ? EPI_ACCUM : EPI_LINEAR, a, st), "series_gemm<skipsum>");
     return WN_OK;
 }
 

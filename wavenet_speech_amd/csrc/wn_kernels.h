@@ -12,7 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // arbitrary columns.  hipcc still emits one global_load_dwordx4 for it on gfx950.
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kMaxSeg = 20;   // K-segments of one GEMM  (>= 1 + 2*WN_MAX_TAPS)
+constexpr int kMaxSeg = 32;   // K-segments of one GEMM  (>= 1 + 2*WN_MAX_TAPS and >= WN_MAX_STACK_GROUP)
 constexpr int kMaxSlab = 32;  // M-slabs of one GEMM     (WN_MAX_CHANNELS*2 / 64)
 constexpr int kMaxDst = 2;
 constexpr int kColTile = 128; // time steps per wave tile (4 MFMA N-tiles of 32, lane n <-> columns 4n..4n+3)

@@ -110,6 +110,28 @@ def _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dskip, want_dx, 
     return dx, grads
 
 
+def _stack_skip_sum(lib, specs, zs, skip_w, skip_b, S, batch, layout, device):
+    """S = sum_l W_skip_l z_l + sum_l b_skip_l, in groups of <= MAX_STACK_GROUP blocks (one long-K GEMM each)."""
+    bias_total = torch.stack(skip_b).sum(0).contiguous()
+    G = _lib.MAX_STACK_GROUP
+    for g0 in range(0, len(specs), G):
+        idx = range(g0, min(g0 + G, len(specs)))
+        n = len(idx)
+        shape = _lib.SkipSumShape(batch, layout.length, specs[0].ms, n, layout.ld, layout.halo)
+        for i, l in enumerate(idx):
+            shape.channels[i] = specs[l].co
+        nbytes = lib.wn_skipsum_packed_bytes(ctypes.byref(shape))
+        if nbytes == 0:
+            _lib.check(-1, "wn_skipsum_packed_bytes")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        wptrs = (ctypes.c_void_p * n)(*[skip_w[l].data_ptr() for l in idx])
+        zptrs = (ctypes.c_void_p * n)(*[zs[l].ptr for l in idx])
+        _lib.check(lib.wn_skipsum_pack(ctypes.byref(shape), wptrs, _p(bias_total) if g0 == 0 else None, _p(packed),
+                                       _stream()), "wn_skipsum_pack")
+        _lib.check(lib.wn_skipsum_forward(ctypes.byref(shape), _p(packed), zptrs, _p(S), 0 if g0 == 0 else 1, _stream()),
+                   "wn_skipsum_forward")
+
+
 class _ResidualStackFn(torch.autograd.Function):
     """The per-layer loop of WaveNet / RawCTCNet / WaveNetClassifier
     (modules/wavenet.py:98-100, raw_ctcnet.py:138-145, classifier.py:105-112):
@@ -132,7 +154,7 @@ class _ResidualStackFn(torch.autograd.Function):
         load_series(cur.t, x.detach(), layout)
         ms = specs[0].ms
         S = fresh_series(B, ms, layout, dev)
-        saved = []
+        saved, skip_w, skip_b = [], [], []
         zbuf = None
         for l, spec in enumerate(specs):
             if spec.ms != ms:
@@ -148,11 +170,17 @@ class _ResidualStackFn(torch.autograd.Function):
                 if zbuf is None or zbuf.channels != spec.co:
                     zbuf = Lease(B, spec.co, layout, dev)
                 z = zbuf
-            _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(cur), _p(r), _p(S), 1,
-                                            _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
+            # training keeps every block's z, so skips_sum is formed afterwards by one long-K product over all
+            # blocks (wn_skipsum_forward); inference accumulates per block and keeps a single z scratch buffer
+            _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(cur), _p(r), None if training else _p(S),
+                                            1, _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
             if training:
                 saved.append((cur, ta, sg, z, packed, shape))
+                skip_w.append(params[6])
+                skip_b.append(params[7])
             cur = r
+        if training:
+            _stack_skip_sum(lib, specs, [sv[3] for sv in saved], skip_w, skip_b, S, B, layout, dev)
         ctx.specs, ctx.saved, ctx.layout, ctx.batch = specs, saved, layout, B
         ctx.param_shapes = [tuple(t.shape) for t in flat]
         # hand autograd a tensor of its own: views of internal buffers must never escape a custom Function
