@@ -86,10 +86,12 @@ def test_flat_buffer_single_process_semantics():
     for k in params:
         if ref[k].grad is not None:
             assert torch.equal(params[k].grad, ref[k].grad)
-    # zero_grad(set_to_none=True) by an optimizer must not break the views
-    for p in params.values():
-        p.grad = None
+    # a second step through the same object: grads are re-pointed at the flat buffer every time
     sync.zero()
+    assert all(p.grad is None for p in sync.params)
     _loss(params, x, cot).backward()
     sync.reduce()
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    for k in params:
+        if ref[k].grad is not None:
+            assert torch.equal(params[k].grad, ref[k].grad)

@@ -19,15 +19,18 @@ def shard_bounds(global_batch, rank, world):
 
 
 class FlatGradAllReduce(object):
-    """Keeps `p.grad` of every parameter as a view into one flat buffer and all-reduces that buffer.
+    """All parameter gradients of a replica in ONE flat buffer, all-reduced with ONE collective.
 
         sync = FlatGradAllReduce(model.parameters())
         for batch in ...:
-            sync.zero()                 # instead of optimizer.zero_grad()
+            sync.zero()                 # instead of optimizer.zero_grad(): grads -> None (no memset, and autograd then
+                                        #   ASSIGNS each gradient instead of launching one add kernel per parameter)
             loss(model(batch)).backward()
-            sync.reduce()               # sum over ranks, then / world  (== grad of the global-batch mean loss
-                                        #  when each rank's loss is averaged over its own shard)
+            sync.reduce()               # gather into the flat buffer (one multi-tensor copy), all-reduce (sum),
+                                        #   / world, and point every p.grad at its slice of the buffer
             optimizer.step()
+
+    With each rank's loss averaged over its own shard, the result equals the gradient of the global-batch mean loss.
     """
 
     def __init__(self, params, group=None, average=True):
@@ -40,25 +43,32 @@ class FlatGradAllReduce(object):
         off = 0
         self.views = []
         for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            p.grad = v
-            self.views.append(v)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
-        for p, v in zip(self.params, self.views):
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                p.grad = v  # someone (e.g. zero_grad(set_to_none=True)) detached the view: re-attach
+        for p in self.params:
+            p.grad = None
 
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def gather(self):
+        """copy the freshly computed gradients into the flat buffer and re-point p.grad at the buffer"""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()                     # parameter did not take part in this step
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
     def reduce(self, async_op=False):
-        for p, v in zip(self.params, self.views):  # autograd replaced a view (first backward after None): fold it back
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
+        self.gather()
         if not (dist.is_available() and dist.is_initialized()):
             return None
         w = self.world()
