@@ -113,6 +113,20 @@ def cpu_baseline(channels, cycles, seq_len, budget_s=12.0):
                       % (torch.__version__, channels, len(layers), L_s, seq_len, best)}
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (None if absent)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.csv")
+    key = {"wgrad_kernel": "wgrad_kernel<"}.get(kernel_class)
+    if key is None or not os.path.exists(path):
+        return None
+    total = 0.0
+    for row in csv.DictReader(open(path)):
+        if key in row["kernel"]:
+            total += float(row["avg_bytes_corrected"])
+    return total or None
+
+
 def main():
     args = parse()
     # RCCL / MIOpen print banners on stdout; the contract is ONE JSON line there.  Send fd 1 to stderr for the run
@@ -215,7 +229,9 @@ def main():
         ms, n, fl = kern[dom]
         ach = fl / (ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom),
+                    "traffic_unit": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                                    "separate passes, from profiles/r01/pmc_hbm_traffic.csv (not collected live)",
                     "avg_launch_ms": round(ms / n, 4), "flops_per_launch": fl / n}
     kernel_ms = sum(v[0] for v in kern.values())
     roofline_step = {

@@ -27,3 +27,7 @@ rows.sort(key=lambda r: -r[2])
 print("%-60s %7s %10s %10s" % ("op", "count", "dev ms", "cpu ms"))
 for k, n, d, c in rows[:45]:
     print("%-60s %7d %10.3f %10.3f" % (k[:60], n, d, c))
+print("---- CPU-side ops that launch fill kernels")
+for e in prof.key_averages(group_by_stack_n=0):
+    if any(s in e.key for s in ("zero", "fill", "zeros")):
+        print("%-50s count %5d cpu ms %.3f" % (e.key[:50], e.count, e.cpu_time_total / 1e3))
