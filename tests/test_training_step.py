@@ -1,0 +1,53 @@
+"""The training-step plumbing around the hot path (wavenet_speech_amd/training.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from wavenet_speech_amd import training as T
+
+
+def test_ctc_known_answer_of_the_reference():
+    """tests/test_classifier.py:53-59 in the reference: warp-ctc on a 2-step toy gives ~2.4628"""
+    probs = torch.tensor([[[0.1, 0.6, 0.1, 0.1, 0.1]], [[0.1, 0.1, 0.6, 0.1, 0.1]]])  # (T=2, B=1, C=5) activations
+    trans = probs.permute(1, 2, 0).contiguous()                                          # [B, C, T]
+    got = T.ctc_total(trans, torch.tensor([[1, 2]]), torch.tensor([2]))
+    assert abs(float(got) - 2.4628) < 1e-3
+
+
+def test_sequence_nll_equals_the_reference_loop():
+    torch.manual_seed(0)
+    pred = torch.randn(3, 7, 11)
+    target = torch.randint(0, 7, (3, 11))
+    loop = sum(F.cross_entropy(pred[:, :, t], target[:, t]) for t in range(11))      # Loss.py:41-42
+    assert torch.allclose(T.sequence_nll(pred, target), loop, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_joint_step_matches_oracle_losses_and_learns():
+    from oracle import wavenet_oracle as O
+    from wavenet_speech_amd.modules import WaveNet, WaveNetClassifier
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    C, L, B = 16, 121, 2
+    wl = [(C, C, 2, d) for d in (1, 2, 4)]
+    cl = [(12, 12, 2, d) for d in (1, 2)]
+    wavenet = WaveNet(C, 2, wl, C, softmax=False)
+    ctcnet = WaveNetClassifier(C, 5, cl, 12, pool_kernel_size=3, softmax=False)
+    sig = O.one_hot_encoding(torch.randint(0, C, (B, L)), C)
+    seq = torch.randint(0, 4, (B, 6))
+    lengths = torch.tensor([6, 4])
+    # oracle losses on the CPU
+    with torch.no_grad():
+        pred = O.wavenet(sig[:, :, :-1], wavenet.state_dict(), wl, False)
+        trans = O.wavenet_classifier(pred, ctcnet.state_dict(), cl, 3, 1, False)
+        xe0 = T.sequence_nll(pred, sig[:, :, 1:].argmax(1)) / L
+        ctc0 = T.ctc_total(trans, seq + 1, lengths) / trans.shape[2]
+    wavenet, ctcnet = wavenet.to(dev), ctcnet.to(dev)
+    opt = torch.optim.Adam(list(wavenet.parameters()) + list(ctcnet.parameters()), lr=3e-3)
+    first = T.train_step(wavenet, ctcnet, sig.to(dev), seq.to(dev), lengths.to(dev), opt)
+    assert abs(first[0] - float(xe0)) < 1e-4 * max(1.0, abs(float(xe0)))
+    assert abs(first[1] - float(ctc0)) < 1e-4 * max(1.0, abs(float(ctc0)))
+    last = first
+    for _ in range(30):
+        last = T.train_step(wavenet, ctcnet, sig.to(dev), seq.to(dev), lengths.to(dev), opt)
+    assert last[2] < 0.8 * first[2]          # "you should see a gradually decreasing loss" (reference tests)
