@@ -108,3 +108,14 @@ def test_shard_bounds_cover_the_batch():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [e - b for b, e in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_series_pool_is_capped_and_lru():
+    from wavenet_speech_amd import series
+    pool = series._Pool()
+    pool.cap_bytes = 10 * 4 * 100                       # room for ten 100-float buffers
+    for i in range(30):                                 # thirty distinct "sequence lengths"
+        pool.give(("cpu", 1, 8, 100 + i, 0, 128), torch.zeros(100))
+    assert pool.free_bytes <= pool.cap_bytes
+    assert pool.take(("cpu", 1, 8, 100, 0, 128)) is None          # the oldest shapes were dropped
+    assert pool.take(("cpu", 1, 8, 129, 0, 128)) is not None      # the newest survive

@@ -8,6 +8,10 @@
 // 16 B per channel row), transposed through LDS (row pitch 36 floats: conflict-free 16-byte
 // fragment reads), and each lane then reads its channel's 16 consecutive time steps.
 //
+// The LDS image is double-buffered (2 x 72 KB at WT=4) and the chunk loop is software-pipelined by hand: the next
+// chunk's ds_writes, the HBM loads of the chunk after it and every operand-fragment read sit in the shadow of the
+// MFMAs (sched_group_barrier pins the interleave), one barrier per chunk.
+//
 // Workgroup = 4 waves (2 x 2), each wave owns a (WT*32) x (WT*32) output tile in AGPRs
 // (256 accumulator registers at WT=4, i.e. a 256 x 256 tile per workgroup = a whole C x C
 // matrix at C=256).  Split-K over time: workgroup `split` handles a contiguous range of
@@ -27,9 +31,9 @@ template <int WT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int ROWS = 2 * WT * 32;   // rows of the A tile and of the B tile held by the workgroup
     constexpr int PASSES = ROWS / 32;   // staging passes: 32 rows x 32 steps per pass (256 threads x float4)
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * kPitch];
-    float* As = lds;
-    float* Bs = lds + ROWS * kPitch;
+    constexpr int STAGE = 2 * ROWS * kPitch;   // floats of one LDS stage (A tile + B tile)
+    // two stages: while the MFMAs consume stage s, the next chunk is written into stage s^1 (one barrier per chunk)
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -49,24 +53,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int c_end = (int)((long long)a.nchunk * (split + 1) / a.nsplit);
 
     // ---- staging geometry ---------------------------------------------------------------------
+    // thread (trow, tc) stages row q*32+trow, steps 4tc..4tc+3 of every pass q.  Its byte offsets inside a chunk are
+    // constant, so a load is  wave-uniform chunk base (SGPRs) + 32-bit per-thread offset : no VALU per load.
     const int trow = tid >> 3, tc = tid & 7;
     const int ld = a.ld;
+    unsigned offA[PASSES], offB[PASSES];
+    bool okA[PASSES], okB[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+        const int ar = tm * ROWS + q * 32 + trow, br = tn * ROWS + q * 32 + trow;
+        okA[q] = ar < pr.a_cp;
+        okB[q] = br < pr.b_cp;
+        offA[q] = (unsigned)(((okA[q] ? ar : 0) * ld + 4 * tc) * 4);
+        offB[q] = (unsigned)(((okB[q] ? br : 0) * ld + 4 * tc) * 4);
+    }
     f32x4 ra[PASSES], rb[PASSES];
     float rs[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) rs[q] = 0.0f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int c) {
-        const int b = c / a.chunks_per_row;
-        const long col = (long)a.halo + (long)(c - b * a.chunks_per_row) * kChunk + 4 * tc;
-#pragma unroll
-        for (int q = 0; q < PASSES; ++q) {
-            const int ar = tm * ROWS + q * 32 + trow;
-            const int br = tn * ROWS + q * 32 + trow;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            ra[q] = ar < pr.a_cp ? *reinterpret_cast<const f32x4*>(pr.A + ((long)b * pr.a_cp + ar) * ld + col) : zero;
-            rb[q] = br < pr.b_cp ? *reinterpret_cast<const f32x4u*>(pr.Bm + ((long)b * pr.b_cp + br) * ld + col + pr.off) : zero;
-        }
+    const char* baseA = nullptr;   // wave-uniform byte bases of the chunk being loaded
+    const char* baseB = nullptr;
+    // (utterance, chunk-in-row) of the next chunk to fetch, advanced incrementally (no division in the loop)
+    int nb = c_begin / a.chunks_per_row, ncc = c_begin - nb * a.chunks_per_row;
+    auto next_chunk = [&](bool advance) {   // branch-free: past the end the last chunk is simply fetched again
+        const long col = (long)a.halo + (long)ncc * kChunk;
+        baseA = reinterpret_cast<const char*>(pr.A + (long)nb * pr.a_cp * ld + col);
+        baseB = reinterpret_cast<const char*>(pr.Bm + (long)nb * pr.b_cp * ld + col + pr.off);
+        const int n1 = ncc + 1;
+        const bool wrap = n1 == a.chunks_per_row;
+        ncc = advance ? (wrap ? 0 : n1) : ncc;
+        nb = advance ? (wrap ? nb + 1 : nb) : nb;
+    };
+    auto load_a = [&](int q) { ra[q] = *reinterpret_cast<const f32x4*>(baseA + offA[q]); };
+    auto load_b = [&](int q) { rb[q] = *reinterpret_cast<const f32x4u*>(baseB + offB[q]); };
+    // registers -> LDS stage st ([row][t], pitch 36), + row sums of A (`real` = 0 for the duplicate chunk that the
+    // branch-free tail iteration stages, so that it is not counted twice)
+    auto write_a = [&](int st, int q, float real) {
+        const f32x4 v = okA[q] ? ra[q] : zero4;
+        *reinterpret_cast<f32x4*>(&lds[st * STAGE + (q * 32 + trow) * kPitch + 4 * tc]) = v;
+        rs[q] += real * ((v[0] + v[1]) + (v[2] + v[3]));
+    };
+    auto write_b = [&](int st, int q) {
+        const f32x4 v = okB[q] ? rb[q] : zero4;
+        *reinterpret_cast<f32x4*>(&lds[st * STAGE + ROWS * kPitch + (q * 32 + trow) * kPitch + 4 * tc]) = v;
     };
 
     f32x16 acc[WT][WT];
@@ -77,36 +108,80 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
 
-    if (c_begin < c_end) issue(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();  // everyone finished reading the previous stage
-#pragma unroll
-        for (int q = 0; q < PASSES; ++q) {
-            *reinterpret_cast<f32x4*>(&As[(q * 32 + trow) * kPitch + 4 * tc]) = ra[q];
-            *reinterpret_cast<f32x4*>(&Bs[(q * 32 + trow) * kPitch + 4 * tc]) = rb[q];
-            rs[q] += (ra[q][0] + ra[q][1]) + (ra[q][2] + ra[q][3]);
-        }
-        __syncthreads();
-        if (c + 1 < c_end) issue(c + 1);  // next stage's HBM loads fly under this stage's MFMAs
+    // lane (i, h) contracts time steps 16h .. 16h+15 of a chunk, four (one "sub-step") at a time.
+    // fragment piece j of a set: j < WT -> A rows of row-tile j, else B rows of column-tile j-WT
+    auto load_frag = [&](int st, int sub, int j, f32x4 (&fa)[WT], f32x4 (&fb)[WT]) {
+        const float* As = lds + st * STAGE;
+        const float* Bs = As + ROWS * kPitch;
+        if (j < WT)
+            fa[j] = *reinterpret_cast<const f32x4*>(&As[((wm * WT + j) * 32 + i) * kPitch + 16 * h + 4 * sub]);
+        else
+            fb[j - WT] = *reinterpret_cast<const f32x4*>(&Bs[((wn_ * WT + (j - WT)) * 32 + i) * kPitch + 16 * h + 4 * sub]);
+    };
 
-        // lane (i, h) contracts time steps 16h .. 16h+15 of the chunk, four at a time
+    // ---- software pipeline -----------------------------------------------------------------------
+    // Per 32-step chunk each wave issues 4 regions of 4*WT*WT MFMAs (one per 4-step sub-step).  A region is cut into
+    // G = 4*WT groups of WT MFMAs; each group is fenced with sched_barrier and given at most one memory instruction,
+    // which therefore issues in the shadow of the previous group's MFMAs (an fp32 MFMA holds the pipe for 64 cycles):
+    //   region 0: MFMA(sub 0) || group g: ds_write piece g of chunk c+1 -> stage st^1 ; ds_read frags sub 1
+    //   region 1: MFMA(sub 1) || group g: HBM load piece g of chunk c+2 -> registers  ; ds_read frags sub 2
+    //   region 2: MFMA(sub 2) || ds_read frags sub 3 ;  BARRIER (stage st consumed by all, stage st^1 complete)
+    //   region 3: MFMA(sub 3) || ds_read frags sub 0 of chunk c+1 (stage st^1)
+    constexpr int G = 4 * WT;
+    f32x4 fa0[WT], fb0[WT], fa1[WT], fb1[WT];
+    auto region = [&](const f32x4 (&fa)[WT], const f32x4 (&fb)[WT], auto&& side) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            f32x4 fa[WT], fb[WT];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int m = 0; m < WT; ++m)
-                fa[m] = *reinterpret_cast<const f32x4*>(&As[((wm * WT + m) * 32 + i) * kPitch + 16 * h + 4 * sub]);
+            for (int m = 0; m < WT; ++m) {
+                side(s * WT + m);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nn = 0; nn < WT; ++nn)
-                fb[nn] = *reinterpret_cast<const f32x4*>(&Bs[((wn_ * WT + nn) * 32 + i) * kPitch + 16 * h + 4 * sub]);
+                for (int nn = 0; nn < WT; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][s], fb[nn][s], acc[m][nn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    if (c_begin < c_end) {
+        next_chunk(c_begin + 1 < c_end);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < PASSES; ++q) { load_a(q); load_b(q); }
 #pragma unroll
-                for (int m = 0; m < WT; ++m)
+        for (int q = 0; q < PASSES; ++q) { write_a(0, q, 1.0f); write_b(0, q); }
+        next_chunk(c_begin + 2 < c_end);
 #pragma unroll
-                    for (int nn = 0; nn < WT; ++nn)
-                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][s], fb[nn][s], acc[m][nn], 0, 0, 0);
-        }
+        for (int q = 0; q < PASSES; ++q) { load_a(q); load_b(q); }
+    }
+    __syncthreads();
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int j = 0; j < 2 * WT; ++j) load_frag(0, 0, j, fa0, fb0);
+    }
+    // The loop body is straight-line code (no branches): with control flow around the loads hipcc falls back to
+    // s_waitcnt vmcnt(0) before every load and LDS write, which serialises the HBM loads (measured: 2.5 ms vs 1.7 ms).
+    // Past the last chunk the same chunk is fetched again and written to a stage nobody reads.
+    for (int c = c_begin; c < c_end; ++c) {
+        const int st = (c - c_begin) & 1;
+        const float real = c + 1 < c_end ? 1.0f : 0.0f;
+        // region 0: registers hold chunk c+1 (loaded during chunk c-1's MFMAs) -> stage st^1
+        region(fa0, fb0, [&](int g) {
+            if (g & 1) write_b(st ^ 1, g >> 1); else write_a(st ^ 1, g >> 1, real);
+            if (g >= G - 2 * WT) load_frag(st, 1, g - (G - 2 * WT), fa1, fb1);
+        });
+        // region 1: HBM loads of chunk c+2 fly under the MFMAs and across the barrier
+        next_chunk(c + 3 < c_end);
+        region(fa1, fb1, [&](int g) {
+            if (g & 1) load_b(g >> 1); else load_a(g >> 1);
+            if (g < 2 * WT) load_frag(st, 2, g, fa0, fb0);
+        });
+        region(fa0, fb0, [&](int g) {
+            if (g < 2 * WT) load_frag(st, 3, g, fa1, fb1);
+        });
+        __syncthreads();   // every wave has read all of stage st and written all of stage st^1
+        region(fa1, fb1, [&](int g) {
+            if (g < 2 * WT) load_frag(st ^ 1, 0, g, fa0, fb0);
+        });
     }
 
     // ---- write the partial tile to this split's slab --------------------------------------------

@@ -3,6 +3,8 @@ Padded series layout (see include/wavenet_amd.h): device buffers float[B][round_
 valid [C][L] window starts at column `halo`; everything else is zero and stays zero (the kernels
 only ever write the valid window).  torch is used here purely as the device allocator.
 """
+import collections
+import os
 import threading
 
 import torch
@@ -29,28 +31,44 @@ class _Pool(object):
     """Free-list of zero-padded series buffers.  A buffer handed out by `lease` goes back to the pool when
     its Lease is garbage collected (i.e. when the autograd context that saved it dies), so several forward
     passes may be in flight without aliasing.  Buffers keep their zero padding for life, which is what
-    lets the pool skip the memset a fresh allocation would need."""
+    lets the pool skip the memset a fresh allocation would need.
+
+    Keys are exact shapes (batch, channels, length, halo, ld), so training on variable-length utterances
+    would otherwise accumulate one set of buffers per distinct length: the idle (free) part of the pool is
+    capped (WN_POOL_CAP_GB, default 48) and least-recently-used shapes are dropped first."""
 
     def __init__(self):
-        self._free = {}
+        self._free = collections.OrderedDict()   # key -> list of tensors, most recently used key last
         self._lock = threading.Lock()
-        self.allocated_bytes = 0
+        self.free_bytes = 0
+        self.cap_bytes = int(float(os.environ.get("WN_POOL_CAP_GB", "48")) * (1 << 30))
 
     def take(self, key):
         with self._lock:
             lst = self._free.get(key)
             if lst:
-                return lst.pop()
+                t = lst.pop()
+                self.free_bytes -= t.numel() * 4
+                self._free.move_to_end(key)
+                return t
         return None
 
     def give(self, key, tensor):
         with self._lock:
             self._free.setdefault(key, []).append(tensor)
+            self._free.move_to_end(key)
+            self.free_bytes += tensor.numel() * 4
+            while self.free_bytes > self.cap_bytes and self._free:
+                old_key = next(iter(self._free))
+                if old_key == key and len(self._free) == 1:
+                    break
+                for t in self._free.pop(old_key):
+                    self.free_bytes -= t.numel() * 4
 
     def clear(self):
         with self._lock:
             self._free.clear()
-            self.allocated_bytes = 0
+            self.free_bytes = 0
 
 
 POOL = _Pool()
@@ -67,7 +85,6 @@ class Lease(object):
         t = POOL.take(self._key)
         if t is None:
             t = torch.zeros(batch, cp, layout.ld, dtype=torch.float32, device=device)
-            POOL.allocated_bytes += t.numel() * 4
         self.t = t
         self.ptr = t.data_ptr()
         self.channels = channels
