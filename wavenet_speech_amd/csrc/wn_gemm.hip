@@ -127,27 +127,37 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 
     const float* wp = a.wpacked + sl.woff + lane * 4;
     const long colbase = (long)a.halo + t0 + NT * n;
+    const long lanerow = 4 * h;   // rows 4h..4h+3 of each 8-row k-block belong to this half-wave
     int seg = 0;
     int seg_left = a.seg[0].nkb;
-    const float* bp = a.seg[0].base + ((long)b * a.seg[0].cp + 4 * h) * ld + colbase + a.seg[0].off;
+    const float* bp = a.seg[0].base + ((long)b * a.seg[0].cp + lanerow) * ld + colbase + a.seg[0].off;
+    int a_left = nkb, b_left = nkb;   // k-blocks not yet fetched
 
     f32x4 A[2][MT];    // A[slot][m][q]: A operand of k-step q for row-tile m
     breg_t B[4][4];    // B[slot][q][t]: B operand of k-step q for column-tile t
+    // The fetch helpers are BRANCH-FREE: with control flow around the loads hipcc loses track of the outstanding
+    // loads and waits vmcnt(~0) for the prefetch it has just issued, every k-block (measured: 72 instead of 64
+    // cycles per MFMA).  Past the last k-block the pointers simply stop advancing, so the (PFB + 1) surplus
+    // fetches re-read the last block.
     auto loadA = [&](f32x4 (&dst)[MT]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const f32x4*>(wp + m * 256);
-        wp += MT * 256;
+        const bool more = a_left > 1;
+        wp += more ? MT * 256 : 0;
+        a_left -= more ? 1 : 0;
     };
     auto loadB = [&](breg_t (&dst)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bload_t*>(bp + (long)q * ld);
-        bp += 8 * (long)ld;
-        if (--seg_left == 0) {
+        const bool more = b_left > 1;
+        b_left -= more ? 1 : 0;
+        bp += more ? 8 * (long)ld : 0;
+        seg_left -= more ? 1 : 0;
+        if (more && seg_left == 0) {   // wave-uniform and rare; no vector memory op inside, so the counters stay exact
             ++seg;
-            if (seg < sl.nseg) {
-                seg_left = a.seg[seg].nkb;
-                bp = a.seg[seg].base + ((long)b * a.seg[seg].cp + 4 * h) * ld + colbase + a.seg[seg].off;
-            }
+            const GemmSeg ns = a.seg[seg];
+            seg_left = ns.nkb;
+            bp = ns.base + ((long)b * ns.cp + lanerow) * ld + colbase + ns.off;
         }
     };
     auto compute = [&](const f32x4 (&fa)[MT], const breg_t (&fb)[4]) {
@@ -162,24 +172,31 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 
     loadA(A[0]);
 #pragma unroll
-    for (int p = 0; p < PFB; ++p)
-        if (p < nkb) loadB(B[p]);
+    for (int p = 0; p < PFB; ++p) loadB(B[p]);
 #ifdef WN_STAMPS
     __builtin_amdgcn_sched_barrier(0);
     st_t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    for (int g0 = 0; g0 < nkb; g0 += 4) {
+    int g0 = 0;
+    for (; g0 + 4 <= nkb; g0 += 4) {   // straight-line body: 4 k-blocks = 4 x (MT + 4 loads, MT*NT*4 MFMAs)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int g = g0 + j;
-            if (g < nkb) {
-                if (g + 1 < nkb) loadA(A[(j + 1) & 1]);
-                if (g + PFB < nkb) loadB(B[(j + PFB) & 3]);
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block
-                compute(A[j & 1], B[j & 3]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            loadA(A[(j + 1) & 1]);
+            loadB(B[(j + PFB) & 3]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA block
+            compute(A[j & 1], B[j & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {       // tail: nkb % 4 blocks (the ring continues at slot 0: g0 is a multiple of 4)
+        if (g0 + j < nkb) {
+            loadA(A[(j + 1) & 1]);
+            loadB(B[(j + PFB) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A[j & 1], B[j & 3]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
