@@ -272,7 +272,9 @@ struct WgradPlan {
     void finish(int nchunk) {
         nsplit = std::max(1, 512 / std::max(1, ntile_total));
         nsplit = std::min(nsplit, std::max(1, nchunk));
+        if (nsplit >= 16) nsplit = nsplit / 8 * 8;   // multiple of 8: all tiles of a split go to one XCD (wgrad_kernel)
     }
+    bool xcd_map() const { return nsplit % 8 == 0; }
     size_t bytes() const { return (size_t)nsplit * (size_t)(slab_floats + rs_floats) * 4; }
 };
 inline int pick_wt(int maxdim) { return maxdim > 128 ? 4 : (maxdim > 64 ? 2 : 1); }
@@ -599,7 +601,7 @@ int run_wgrad(const std::vector<PairSpec>& ps, int maxdim, int B, int L, int ld,
         d.b0 = ps[i].rowsum ? ps[i].b0 : nullptr; d.b1 = ps[i].rowsum ? ps[i].b1 : nullptr; d.rs_off = wp.rs_off[i];
         flops += 2.0 * ps[i].a_rows * (double)ps[i].b_rows * (double)B * L;
     }
-    a.npair = wp.npair; a.ntile_total = wp.ntile_total; a.nsplit = wp.nsplit;
+    a.npair = wp.npair; a.ntile_total = wp.ntile_total; a.nsplit = wp.nsplit; a.xcd_map = wp.xcd_map() ? 1 : 0;
     a.B = B; a.L = L; a.ld = ld; a.halo = halo; a.chunks_per_row = cpr; a.nchunk = B * cpr;
     a.slab = reinterpret_cast<float*>(workspace);
     a.rowsum = a.slab + (size_t)wp.nsplit * wp.slab_floats;
@@ -639,10 +641,15 @@ size_t wn_block_wgrad_workspace_bytes(const wn_block_shape* s) {
     int off[WN_MAX_TAPS];
     if (check_block(s, off) != WN_OK) return 0;
     static const float dummy = 0;
-    std::vector<PairSpec> ps = block_pairs(s, off, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr);
+    // the split-K plan depends on the number of pairs, which depends on whether dr is given: cover both
     size_t need = 0;
-    run_wgrad(ps, std::max(std::max(s->in_channels, s->out_channels), s->skip_rows), s->batch, s->length, s->ld,
-              s->halo, nullptr, 0, true, &need, KC_WGRAD, nullptr);
+    for (int with_dr = 0; with_dr < 2; ++with_dr) {
+        std::vector<PairSpec> ps = block_pairs(s, off, &dummy, &dummy, &dummy, &dummy, with_dr ? &dummy : nullptr, &dummy, nullptr);
+        size_t n = 0;
+        run_wgrad(ps, std::max(std::max(s->in_channels, s->out_channels), s->skip_rows), s->batch, s->length, s->ld,
+                  s->halo, nullptr, 0, true, &n, KC_WGRAD, nullptr);
+        need = std::max(need, n);
+    }
     return need;
 }
 

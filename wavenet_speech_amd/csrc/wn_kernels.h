@@ -127,6 +127,7 @@ struct WgradArgs {
     float* rowsum;        // [nsplit][rs_floats]
     long long slab_floats;
     int rs_floats;
+    int xcd_map;          // 1: nsplit % 8 == 0 and all tiles of a split are placed on one XCD
 };
 
 struct ReduceDst {

@@ -41,8 +41,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int wm = wave >> 1, wn_ = wave & 1;
 
     // ---- which (pair, tile, split) -------------------------------------------------------------
-    const int split = blockIdx.x / a.ntile_total;
-    const int tile = blockIdx.x - split * a.ntile_total;
+    // XCD-aware: workgroups id and id+8 share an XCD (and its L2).  All tiles of one time-split read the same
+    // operand chunks (da, dg, dr, x, z are each used by 2-3 pairs), so they are placed on ONE XCD, back to back:
+    // split = (id/8 / ntile) * 8 + id%8, tile = (id/8) % ntile.  nsplit is a multiple of 8 when this mapping is on.
+    int split, tile;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        split = (local / a.ntile_total) * 8 + xcd;
+        tile = local % a.ntile_total;
+    } else {
+        split = blockIdx.x / a.ntile_total;
+        tile = blockIdx.x - split * a.ntile_total;
+    }
     int p = 0;
     while (p + 1 < a.npair && tile >= a.pair[p + 1].tile0) ++p;
     const WgradPair pr = a.pair[p];
