@@ -170,10 +170,18 @@ def test_inference_mode_matches_training_forward():
     layers = [(32, 32, 2, 2 ** i) for i in range(4)]
     net = _mods().WaveNet(16, 2, layers, 32, softmax=True).to(DEV)
     x = torch.randn(2, 16, 300, device=DEV)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
     y_train = net(x)
     with torch.no_grad():
         y_eval = net(x)
-    assert torch.equal(y_train.detach(), y_eval)  # same kernels, same order: bitwise identical
+        y_eval2 = net(x)
+    # training forms skips_sum with one long-K product, inference accumulates it block by block: same math, a
+    # different association of the per-block sums and biases
+    assert O.rel_err(y_train.detach().cpu(), y_eval.cpu()) < 1e-6
+    assert torch.equal(y_eval, y_eval2)
 
 
 def test_two_forwards_in_flight_do_not_alias():

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 
     // ---- accumulators ---------------------------------------------------------------------------
     // EPI_ACCUM (the stack's running skips_sum += ...): the destination tile is loaded straight into the accumulators
-    // here -- all 16*MT loads of a lane in flight at once, no VALU in between -- and the bias is added at store time,
-    // so the epilogue is a plain store.  (A read-modify-write epilogue cost 45 us of a 112 us wave: 64 dependent
+    // here, 8 rows per batch and one batch ahead, with the row's bias added on the way in, so the epilogue is the same
+    // plain store as EPI_LINEAR.  (A read-modify-write epilogue cost 45 us of a 112 us wave: 64 dependent
     // load->add->store rounds; tools/block_stamps.py.)  Every other epilogue starts from the row's bias.
     f32x16 acc[MT][NT];
     if constexpr (EPI == EPI_ACCUM) {
@@ -104,9 +104,11 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
             __builtin_amdgcn_sched_barrier(0);
             const int m = bi / BPT, r0 = (bi % BPT) * RB;
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+            for (int i = 0; i < RB; ++i) {
+                const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r0 + i, h)] : 0.0f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t][r0 + i] = stage[bi & 1][i][t];
+                for (int t = 0; t < NT; ++t) acc[m][t][r0 + i] = stage[bi & 1][i][t] + bv;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
@@ -229,36 +231,24 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 
     if constexpr (EPI == EPI_LINEAR || EPI == EPI_ACCUM) {
         const GemmDst d = a.dst[sl.dst];
-        float* dbase = d.base;
         int he = h;
         if constexpr (EPI == EPI_ACCUM) {
             // opaque to the optimiser: otherwise the row indices / store addresses are CSE'd with the preload's and
-            // kept alive (= spilled) across the whole K loop; they are cheaper to recompute
-            asm volatile("" : "+s"(dbase));
+            // kept alive (= spilled) across the whole K loop; they are cheaper to recompute.  (Only the lane half is
+            // hidden: hiding the pointer itself loses its address space and turns the stores into flat_store +
+            // vmcnt(0) drains.)
             asm volatile("" : "+v"(he));
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            f32x4 bv[4];   // the 16 rows of a lane are 4 groups of 4 consecutive rows: (r&3) + 8*(r>>2) + 4*h
-            if constexpr (EPI == EPI_ACCUM) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    bv[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + sl.boff + 32 * m + 8 * g + 4 * he) : zero;
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = sl.row0 + 32 * m + rowof(r, he);
                 if (row < d.rows) {
-                    float* p = dbase + ((long)b * d.cp + row) * ld + colbase;
+                    float* p = d.base + ((long)b * d.cp + row) * ld + colbase;
                     breg_t v;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r];
-                    if constexpr (EPI == EPI_ACCUM) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) v[t] += bv[r >> 2][r & 3];
-                    }
                     *reinterpret_cast<breg_t*>(p) = clip(v);
                 }
             }
