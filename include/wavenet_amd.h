@@ -168,6 +168,17 @@ int wn_conv_backward_weights(const wn_conv_shape* s, const float* x, const float
                              float* dweight, float* dbias /* may be NULL */,
                              void* workspace, size_t workspace_bytes, wn_stream_t stream);
 
+/* ---- next-sample NLL head: replaces the L-iteration CrossEntropyLoss loop of Loss.py:38-43 /
+ * legacy_code/train.py:37-39.  logits: dense [B][C][L] floats; target: [B][L] int64 class indices.
+ *   forward : lse[b][t] = logsumexp_c logits[b][c][t];  partial[i] = sum over workgroup i of (lse - logits[target])
+ *             (wn_nll_partials(B, L) floats; the caller sums them in order and divides by B: deterministic)
+ *   backward: dlogits = (exp(logits - lse) - onehot(target)) * gscale[0]      (gscale: one DEVICE float, = dloss / B) */
+size_t wn_nll_partials(int batch, int length);
+int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int batch, int classes,
+                   int length, wn_stream_t stream);
+int wn_nll_backward(const float* logits, const long long* target, const float* lse, const float* gscale, float* dlogits,
+                    int batch, int classes, int length, wn_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of every kernel on its launch stream ----
  * Kernel classes: index into wn_prof_kernel_name().  wn_prof_collect() synchronises the recorded
  * events and adds them to the per-class totals; wn_prof_get() reads them. */

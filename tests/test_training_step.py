@@ -51,3 +51,25 @@ def test_joint_step_matches_oracle_losses_and_learns():
     for _ in range(30):
         last = T.train_step(wavenet, ctcnet, sig.to(dev), seq.to(dev), lengths.to(dev), opt)
     assert last[2] < 0.8 * first[2]          # "you should see a gradually decreasing loss" (reference tests)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 7, 11), (2, 256, 1000), (1, 33, 130)])
+def test_fused_nll_head_matches_the_reference_loop(shape):
+    B, C, L = shape
+    torch.manual_seed(4)
+    pred = torch.randn(B, C, L) * 3
+    target = torch.randint(0, C, (B, L))
+    pc = pred.clone().requires_grad_(True)
+    if L <= 200:
+        loop = sum(F.cross_entropy(pc[:, :, t], target[:, t]) for t in range(L))      # the reference's loop
+    else:
+        loop = F.cross_entropy(pc, target, reduction="sum") / B
+    (loop * 1.7).backward()
+    pg = pred.to("cuda:0").requires_grad_(True)
+    got = T.sequence_nll(pg, target.to("cuda:0"))
+    (got * 1.7).backward()
+    assert abs(float(got) - float(loop)) < 1e-5 * max(1.0, abs(float(loop)))
+    assert float((pg.grad.cpu() - pc.grad).abs().max()) < 1e-6 * max(1.0, float(pc.grad.abs().max())) + 1e-7
+    again = T.sequence_nll(pg.detach(), target.to("cuda:0"))
+    assert float(again) == float(got)            # deterministic

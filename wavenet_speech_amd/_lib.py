@@ -74,6 +74,9 @@ SIGNATURES = {
     "wn_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvShape)]),
     "wn_conv_backward_weights": (c_int, [POINTER(ConvShape), c_float_p, c_float_p, c_float_p, c_float_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "wn_nll_partials": (c_size_t, [c_int, c_int]),
+    "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
+    "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
     "wn_prof_enable": (c_int, [c_int]),
     "wn_prof_reset": (c_int, []),
     "wn_prof_collect": (c_int, []),

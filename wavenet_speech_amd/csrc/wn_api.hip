@@ -825,6 +825,30 @@ int wn_conv_backward_weights(const wn_conv_shape* s, const float* x, const float
 }
 
 // ------------------------------------------------------------------------------------------
+// next-sample NLL head
+// ------------------------------------------------------------------------------------------
+size_t wn_nll_partials(int batch, int length) {
+    if (batch <= 0 || length <= 0) return 0;
+    return (size_t)(((long long)batch * ((length + 3) / 4) + 255) / 256);
+}
+
+int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int batch, int classes,
+                   int length, wn_stream_t stream) {
+    if (batch <= 0 || classes <= 0 || length <= 0) return WN_ERR_BAD_SHAPE;
+    if (!logits || !target || !lse || !partial) return WN_ERR_NULL;
+    WN_HIP(launch_nll_forward(logits, target, lse, partial, batch, classes, length, (hipStream_t)stream), "nll_forward");
+    return WN_OK;
+}
+
+int wn_nll_backward(const float* logits, const long long* target, const float* lse, const float* gscale, float* dlogits,
+                    int batch, int classes, int length, wn_stream_t stream) {
+    if (batch <= 0 || classes <= 0 || length <= 0) return WN_ERR_BAD_SHAPE;
+    if (!logits || !target || !lse || !gscale || !dlogits) return WN_ERR_NULL;
+    WN_HIP(launch_nll_backward(logits, target, lse, gscale, dlogits, batch, classes, length, (hipStream_t)stream), "nll_backward");
+    return WN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // profiling hooks
 // ------------------------------------------------------------------------------------------
 int wn_prof_enable(int on) {

@@ -330,6 +330,40 @@ def dilated_conv(x, weight, bias, dilation=1, causal=True):
     return _DilatedConvFn.apply(x, weight, bias, int(dilation), bool(causal))
 
 
+class _SequenceNLLFn(torch.autograd.Function):
+    """sum_t mean_b CE(logits[:, :, t], target[:, t])  (Loss.py:38-43) as one fused HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lib = _lib.load()
+        _require_device(logits, "logits")
+        if target.dtype != torch.int64 or not target.is_cuda:
+            raise RuntimeError("wavenet_speech_amd: target must be an int64 device tensor")
+        B, C, L = logits.shape
+        x = logits.detach().contiguous()
+        tg = target.contiguous()
+        lse = torch.empty(B, L, dtype=torch.float32, device=x.device)
+        partial = torch.empty(lib.wn_nll_partials(B, L), dtype=torch.float32, device=x.device)
+        _lib.check(lib.wn_nll_forward(_p(x), _p(tg), _p(lse), _p(partial), B, C, L, _stream()), "wn_nll_forward")
+        ctx.save_for_backward(x, tg, lse)
+        return partial.sum() / B
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, tg, lse = ctx.saved_tensors
+        B, C, L = x.shape
+        gscale = (g / B).to(torch.float32).reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(lib.wn_nll_backward(_p(x), _p(tg), _p(lse), _p(gscale), _p(dx), B, C, L, _stream()), "wn_nll_backward")
+        return dx, None
+
+
+def sequence_nll(logits, target):
+    return _SequenceNLLFn.apply(logits, target)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # measurement hooks
 # ------------------------------------------------------------------------------------------------------------------

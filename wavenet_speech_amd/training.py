@@ -19,7 +19,11 @@ import torch.nn.functional as F
 
 def sequence_nll(pred, target):
     """sum over time of the batch-averaged cross entropy (Loss.py:38-43, legacy_code/train.py:37-39).
-    pred: [B, C, L] logits, target: [B, L] int64."""
+    pred: [B, C, L] logits, target: [B, L] int64.  Device tensors go through the fused HIP kernel
+    (functional.sequence_nll); the torch expression is the CPU form used by the tests."""
+    if pred.is_cuda:
+        from . import functional as HF
+        return HF.sequence_nll(pred, target)
     return F.cross_entropy(pred, target, reduction="sum") / pred.shape[0]
 
 
