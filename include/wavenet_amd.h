@@ -43,7 +43,7 @@ typedef void* wn_stream_t; /* hipStream_t */
 typedef enum wn_status {
     WN_OK = 0,
     WN_ERR_BAD_SHAPE = -1,   /* non-positive / inconsistent dimension, or layout (ld, halo) too small for the taps */
-    WN_ERR_UNSUPPORTED = -2, /* kernel_width > WN_MAX_TAPS or channel count > WN_MAX_CHANNELS */
+    WN_ERR_UNSUPPORTED = -2, /* kernel_width > WN_MAX_TAPS, channels > WN_MAX_CHANNELS, or channels*ld*4 >= 2^32 */
     WN_ERR_NULL = -3,        /* a required pointer is NULL */
     WN_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed (see wn_last_hip_error) */
     WN_ERR_WORKSPACE = -5    /* workspace smaller than wn_*_workspace_bytes() */

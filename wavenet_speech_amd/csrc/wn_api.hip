@@ -581,6 +581,9 @@ int run_wgrad(const std::vector<PairSpec>& ps, int maxdim, int B, int L, int ld,
     wp.finish(B * cpr);
     if (need) *need = wp.bytes();
     if (dry) return WN_OK;
+    // wgrad_kernel addresses a chunk as a wave-uniform base + a 32-bit per-thread byte offset (row * ld + column) * 4
+    for (const PairSpec& p : ps)
+        if ((double)cp8(std::max(p.a_rows, p.b_rows)) * (double)ld * 4.0 >= 4294967296.0) return WN_ERR_UNSUPPORTED;
     if (ps.empty()) return WN_OK;
     if (!workspace) return WN_ERR_NULL;
     if (workspace_bytes < wp.bytes()) return WN_ERR_WORKSPACE;

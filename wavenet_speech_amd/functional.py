@@ -30,6 +30,21 @@ class BlockSpec(object):
         return max(abs(o) for o in self.offsets())
 
 
+def _on_device_of_first_tensor(fn):
+    """Run an autograd.Function forward/backward with the CUDA/HIP device of its first tensor argument current, so
+    that torch.cuda.current_stream() and the kernel launches of the C ABI target the device that owns the buffers."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *args):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None:
+            return fn(ctx, *args)
+        with torch.cuda.device(dev):
+            return fn(ctx, *args)
+    return wrapper
+
+
 def _require_device(t, what):
     if not t.is_cuda:
         raise RuntimeError("wavenet_speech_amd: %s is a CPU tensor; the HIP path needs ROCm device tensors "
@@ -139,6 +154,7 @@ class _ResidualStackFn(torch.autograd.Function):
     with the bottleneck folded into the skip projection by the caller.  Returns skips_sum [B, Ms, L]."""
 
     @staticmethod
+    @_on_device_of_first_tensor
     def forward(ctx, x, specs, *flat):
         lib = _lib.load()
         _require_device(x, "input")
@@ -188,6 +204,7 @@ class _ResidualStackFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_on_device_of_first_tensor
     def backward(ctx, d_skips):
         lib = _lib.load()
         specs, layout, B = ctx.specs, ctx.layout, ctx.batch
@@ -220,6 +237,7 @@ class _ResidualBlockFn(torch.autograd.Function):
     """Stand-alone ResidualBlock.forward (modules/block.py:54-82): returns (residual_out, skip_out)."""
 
     @staticmethod
+    @_on_device_of_first_tensor
     def forward(ctx, x, spec, *params):
         lib = _lib.load()
         _require_device(x, "input")
@@ -248,6 +266,7 @@ class _ResidualBlockFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_on_device_of_first_tensor
     def backward(ctx, d_r, d_s):
         lib = _lib.load()
         spec, layout, B = ctx.spec, ctx.layout, ctx.batch
@@ -272,6 +291,7 @@ class _DilatedConvFn(torch.autograd.Function):
     """CausalConv1d / NonCausalConv1d forward (modules/conv_ops.py:39-44, 73-79); k=1 gives a 1x1 Conv1d."""
 
     @staticmethod
+    @_on_device_of_first_tensor
     def forward(ctx, x, weight, bias, dilation, causal):
         lib = _lib.load()
         _require_device(x, "input")
@@ -302,6 +322,7 @@ class _DilatedConvFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_on_device_of_first_tensor
     def backward(ctx, d_y):
         lib = _lib.load()
         xin, packed, shape = ctx.saved
@@ -334,6 +355,7 @@ class _SequenceNLLFn(torch.autograd.Function):
     """sum_t mean_b CE(logits[:, :, t], target[:, t])  (Loss.py:38-43) as one fused HIP pass each way."""
 
     @staticmethod
+    @_on_device_of_first_tensor
     def forward(ctx, logits, target):
         lib = _lib.load()
         _require_device(logits, "logits")
@@ -350,6 +372,7 @@ class _SequenceNLLFn(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_on_device_of_first_tensor
     def backward(ctx, g):
         lib = _lib.load()
         x, tg, lse = ctx.saved_tensors
