@@ -230,8 +230,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     if (idx < mn && d.w) {
         const int m = (int)(idx / d.N), n = (int)(idx - (long long)m * d.N);
         const float* src = a.slab + d.slab_off + (long long)m * d.Np + n;
+        // fixed summation order (split 0, 1, 2, ...: bitwise reproducible), but eight loads in flight at a time
         float v = 0.0f;
-        for (int s = 0; s < a.nsplit; ++s) v += src[(long long)s * a.slab_floats];
+        int s = 0;
+        for (; s + 8 <= a.nsplit; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(long long)(s + u) * a.slab_floats];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; s < a.nsplit; ++s) v += src[(long long)s * a.slab_floats];
         d.w[(long long)m * d.sm + (long long)n * d.sn] = v;
     }
     if (idx < d.M && (d.b0 || d.b1)) {
