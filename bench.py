@@ -103,13 +103,13 @@ def cpu_baseline(channels, cycles, seq_len, budget_s=12.0):
     log("cpu baseline probe: %d steps in %.2f s on %d threads" % (probe_len, t_probe, ncores))
     L_s = int(min(seq_len, max(probe_len, budget_s / (t_probe / probe_len))))
     times = []
-    for _ in range(2):
+    for _ in range(4):
         times.append(run(L_s))
         log("cpu baseline: %d steps in %.2f s" % (L_s, times[-1]))
     best = min(times)
     return {"value": (L_s / float(seq_len)) / best, "unit": "samples/s", "cores": ncores, "kind": "port",
             "sample": "oracle (ATen conv1d/einsum, fp32, torch %s) fwd+bwd, batch 1, %d ch x %d blocks, %d of %d time "
-                      "steps per iteration (cost linear in L), best of 2 timed iterations after warm-up: %.2f s"
+                      "steps per iteration (cost linear in L), best of 4 timed iterations after warm-up: %.2f s"
                       % (torch.__version__, channels, len(layers), L_s, seq_len, best)}
 
 
