@@ -35,13 +35,16 @@ class _Pool(object):
 
     Keys are exact shapes (batch, channels, length, halo, ld), so training on variable-length utterances
     would otherwise accumulate one set of buffers per distinct length: the idle (free) part of the pool is
-    capped (WN_POOL_CAP_GB, default 48) and least-recently-used shapes are dropped first."""
+    capped (WN_POOL_CAP_GB; default 45 % of the device's memory, so that the saved activations of one step of the
+    largest configurations -- 36 GB at 256 ch x 30 blocks x 16 x 16k, 48 GB at 512 ch x 60 blocks x 2 x 48k -- are
+    recycled rather than re-zeroed) and least-recently-used shapes are dropped first."""
 
     def __init__(self):
         self._free = collections.OrderedDict()   # key -> list of tensors, most recently used key last
         self._lock = threading.Lock()
         self.free_bytes = 0
-        self.cap_bytes = int(float(os.environ.get("WN_POOL_CAP_GB", "48")) * (1 << 30))
+        env = os.environ.get("WN_POOL_CAP_GB")
+        self.cap_bytes = int(float(env) * (1 << 30)) if env else None   # None: resolved on first use
 
     def take(self, key):
         with self._lock:
@@ -53,12 +56,22 @@ class _Pool(object):
                 return t
         return None
 
+    def _cap(self, tensor):
+        if self.cap_bytes is None:
+            try:
+                total = torch.cuda.get_device_properties(tensor.device).total_memory if tensor.is_cuda else 64 << 30
+            except Exception:
+                total = 64 << 30
+            self.cap_bytes = int(0.45 * total)
+        return self.cap_bytes
+
     def give(self, key, tensor):
+        cap = self._cap(tensor)
         with self._lock:
             self._free.setdefault(key, []).append(tensor)
             self._free.move_to_end(key)
             self.free_bytes += tensor.numel() * 4
-            while self.free_bytes > self.cap_bytes and self._free:
+            while self.free_bytes > cap and self._free:
                 old_key = next(iter(self._free))
                 if old_key == key and len(self._free) == 1:
                     break
