@@ -1,0 +1,60 @@
+"""The synthetic signal generator (wavenet_speech_amd/synthetic.py) and, on the GPU, BASELINE.json configs[0]: the
+reference's tests/wavenet_overfit_test.py scenario (tiny WaveNet, one synthetic one-hot signal, per-step NLL, Adadelta
+with ReduceLROnPlateau) -- 'you should see a decreasing loss'."""
+import numpy as np
+import pytest
+import torch
+
+from wavenet_speech_amd import synthetic as S
+
+
+def test_generator_shapes_and_determinism():
+    g = torch.Generator().manual_seed(5)
+    levels, one_hot, bases = S.gaussian_kmer_signal(3, 100, num_levels=32, generator=g)
+    assert levels.shape == (3, 100) and one_hot.shape == (3, 32, 100) and bases.shape[0] == 3
+    assert int(levels.min()) >= 0 and int(levels.max()) <= 31
+    assert torch.equal(one_hot.sum(1), torch.ones(3, 100)) and torch.equal(one_hot.argmax(1), levels)
+    assert int(bases.min()) >= 1 and int(bases.max()) <= 4
+    g2 = torch.Generator().manual_seed(5)
+    levels2, _, _ = S.gaussian_kmer_signal(3, 100, num_levels=32, generator=g2)
+    assert torch.equal(levels, levels2)
+    # each k-mer is held for `upsampling` samples: the signal is piecewise stationary, so neighbouring samples inside a
+    # segment are closer than across the whole read
+    lv = levels.float()
+    assert float((lv[:, 1:] - lv[:, :-1]).abs().mean()) < float((lv - lv.mean(1, keepdim=True)).abs().mean()) * 1.5
+
+
+def test_quantisation_matches_numpy_digitize():
+    x = torch.linspace(-0.999, 0.999, 1001)
+    mapped = S.mu_law(x, 256.0)
+    edges = torch.linspace(-1.0, 1.0, 256)
+    ours = torch.bucketize(mapped, edges, right=True)
+    ref = np.digitize(mapped.numpy(), edges.numpy())              # utils/gaussian_kmer_model.py:86
+    assert np.array_equal(ours.numpy(), ref)
+    assert torch.all(mapped[1:] >= mapped[:-1])                    # mu-law is monotone
+
+
+@pytest.mark.gpu
+def test_config0_wavenet_overfit_script():
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    from wavenet_speech_amd import training as T
+    from wavenet_speech_amd.modules.wavenet import WaveNet
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    _, signal, _ = S.gaussian_kmer_signal(1, 401, num_levels=32, generator=g, device=dev)   # generated on the GPU
+    source, target = signal[:, :, :-1].contiguous(), signal[:, :, 1:].argmax(1)
+    net = WaveNet(32, 2, [(32, 32, 2, d) for d in (1, 2, 4, 8, 16)], 32, softmax=False).to(dev)
+    opt = torch.optim.Adadelta(net.parameters(), lr=1.0, rho=0.9, weight_decay=1e-4)   # wavenet_overfit_test.py:33-37
+    sched = ReduceLROnPlateau(opt, patience=5)
+    losses = []
+    for step in range(80):
+        opt.zero_grad()
+        loss = T.sequence_nll(net(source), target)               # the reference sums CE over time steps (:49-50)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()) / target.shape[1])
+        if step % 20 == 0:
+            sched.step(losses[-1])
+    assert losses[0] > 2.5                                        # ~ln(32) at initialisation
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
