@@ -60,4 +60,4 @@ def train_step(wavenet, ctcnet, sig, seq, lengths, opt, sync=None):
     if sync is not None:
         sync.reduce()
     opt.step()
-    return float(avg_xe), float(avg_ctc), float(avg_joint)
+    return float(avg_xe.detach()), float(avg_ctc.detach()), float(avg_joint.detach())
