@@ -160,7 +160,10 @@ def main():
     torch.manual_seed(0)  # identical replicas
     net = WaveNet(C, 2, layers, C, softmax=False).to(dev)
     nparams = sum(p.numel() for p in net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    try:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)   # same update rule, one multi-tensor kernel
+    except (TypeError, RuntimeError):
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     sync = FlatGradAllReduce(net.parameters())
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # each rank its own shard of the global batch
