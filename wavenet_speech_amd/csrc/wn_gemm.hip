@@ -127,39 +127,58 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     int nkb = 0;
     for (int s = 0; s < sl.nseg; ++s) nkb += a.seg[s].nkb;
 
-    const float* wp = a.wpacked + sl.woff + lane * 4;
-    const long colbase = (long)a.halo + t0 + NT * n;
-    const long lanerow = 4 * h;   // rows 4h..4h+3 of each 8-row k-block belong to this half-wave
+    // Addressing: operands are fetched with BUFFER loads -- a wave-uniform resource (SGPRs: the tensor of the current
+    // segment at this utterance), a wave-uniform running byte offset (one SGPR, advanced by one s_add per k-block)
+    // and a per-lane byte offset that never changes (one VGPR) -- so the loop spends no vector instructions on
+    // pointers.  (Per-lane 64-bit pointers cost ~7 v_lshl_add_u64 per k-block, ~100 of its 4096 MFMA cycles.)
+    constexpr unsigned kRsrcFlags = 0x00020000u;   // gfx9 raw buffer, 32-bit data format
+    auto resource = [&](const float* base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xffffffffu, kRsrcFlags);
+    };
+    const __amdgpu_buffer_rsrc_t wrs = resource(a.wpacked + sl.woff);
+    const unsigned a_off = lane * 16u;
+    unsigned a_soff = 0;
+    const long tilebase = (long)a.halo + t0;       // wave-uniform column of the tile
+    const long colbase = tilebase + NT * n;        // this lane's first column (epilogues)
+    unsigned b_off[4];   // rows 4h..4h+3 of each 8-row k-block belong to this half-wave
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b_off[q] = 4u * ((unsigned)(4 * h + q) * (unsigned)ld + (unsigned)(NT * n));
     int seg = 0;
     int seg_left = a.seg[0].nkb;
-    const float* bp = a.seg[0].base + ((long)b * a.seg[0].cp + lanerow) * ld + colbase + a.seg[0].off;
+    __amdgpu_buffer_rsrc_t brs = resource(a.seg[0].base + (long)b * a.seg[0].cp * ld);
+    unsigned b_soff = 4u * (unsigned)(tilebase + a.seg[0].off);   // halo >= |off|: never negative
     int a_left = nkb, b_left = nkb;   // k-blocks not yet fetched
 
     f32x4 A[2][MT];    // A[slot][m][q]: A operand of k-step q for row-tile m
     breg_t B[4][4];    // B[slot][q][t]: B operand of k-step q for column-tile t
     // The fetch helpers are BRANCH-FREE: with control flow around the loads hipcc loses track of the outstanding
     // loads and waits vmcnt(~0) for the prefetch it has just issued, every k-block (measured: 72 instead of 64
-    // cycles per MFMA).  Past the last k-block the pointers simply stop advancing, so the (PFB + 1) surplus
+    // cycles per MFMA).  Past the last k-block the offsets simply stop advancing, so the (PFB + 1) surplus
     // fetches re-read the last block.
     auto loadA = [&](f32x4 (&dst)[MT]) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const f32x4*>(wp + m * 256);
-        const bool more = a_left > 1;
-        wp += more ? MT * 256 : 0;
-        a_left -= more ? 1 : 0;
+        for (int m = 0; m < MT; ++m)
+            dst[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, a_off + m * 1024u, a_soff, 0));
+        const int more = min(max(a_left - 1, 0), 1);   // 1 while another k-block follows (pure scalar arithmetic)
+        a_soff += more * (MT * 1024u);
+        a_left -= more;
     };
     auto loadB = [&](breg_t (&dst)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bload_t*>(bp + (long)q * ld);
-        const bool more = b_left > 1;
-        b_left -= more ? 1 : 0;
-        bp += more ? 8 * (long)ld : 0;
-        seg_left -= more ? 1 : 0;
-        if (more && seg_left == 0) {   // wave-uniform and rare; no vector memory op inside, so the counters stay exact
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (NT == 4) dst[q] = __builtin_bit_cast(breg_t, __builtin_amdgcn_raw_buffer_load_b128(brs, b_off[q], b_soff, 0));
+            else dst[q] = __builtin_bit_cast(breg_t, __builtin_amdgcn_raw_buffer_load_b64(brs, b_off[q], b_soff, 0));
+        }
+        const int more = min(max(b_left - 1, 0), 1);
+        b_left -= more;
+        b_soff += more * (32u * (unsigned)ld);
+        seg_left -= more;
+        if (more != 0 && seg_left == 0) {   // wave-uniform and rare; no vector memory op inside, so the counters stay exact
             ++seg;
             const GemmSeg ns = a.seg[seg];
             seg_left = ns.nkb;
-            bp = ns.base + ((long)b * ns.cp + lanerow) * ld + colbase + ns.off;
+            brs = resource(ns.base + (long)b * ns.cp * ld);
+            b_soff = 4u * (unsigned)(tilebase + ns.off);
         }
     };
     auto compute = [&](const f32x4 (&fa)[MT], const breg_t (&fb)[4]) {
