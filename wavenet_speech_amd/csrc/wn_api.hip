@@ -106,6 +106,8 @@ int check_layout(int B, int L, int ld, int halo, int max_abs_off) {
     if (halo < 0 || (halo & 3) || (ld & 3)) return WN_ERR_BAD_SHAPE;
     if (halo < max_abs_off) return WN_ERR_BAD_SHAPE;
     if (ld < 2 * halo + rup(L, kColTile)) return WN_ERR_BAD_SHAPE;
+    // the kernels address one utterance's [channels][ld] plane with 32-bit byte offsets (buffer loads)
+    if ((double)WN_MAX_CHANNELS * (double)ld * 4.0 >= 4294967296.0) return WN_ERR_UNSUPPORTED;
     return WN_OK;
 }
 
