@@ -10,12 +10,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k(const float* __restrict__ w, const float* __restrict__ x, float* out,
-                                        unsigned long long* stamps, int nkb, int ld) {
+                                        unsigned long long* stamps, int nkb, int ld, int ncoltile) {
     const int lane = threadIdx.x;
     f32x16 acc[4][4];
     for (int m = 0; m < 4; ++m) for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
     const float* wp = w + lane * 4;
-    const float* bp = x + (size_t)(blockIdx.x % 64) * 128 + (size_t)(4 * (lane >> 5)) * ld + 4 * (lane & 31);
+    const float* bp = x + (size_t)(blockIdx.x % ncoltile) * 128 + (size_t)(4 * (lane >> 5)) * ld + 4 * (lane & 31);
     f32x4 A[2][4], B[2][4];
     for (int m = 0; m < 4; ++m) { A[0][m] = *(const f32x4*)(wp + m * 256); A[1][m] = A[0][m]; }
     for (int q = 0; q < 4; ++q) { B[0][q] = *(const f32x4*)(bp + (size_t)q * ld); B[1][q] = B[0][q]; }
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(64) void k(const float* __restrict__ w, const float
 }
 
 template <int MODE>
-void run(const char* name, float* w, float* x, float* out, unsigned long long* st, int nkb, int ld, int grid) {
+void run(const char* name, float* w, float* x, float* out, unsigned long long* st, int nkb, int ld, int grid, int nct = 64) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld, nct);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(64), 0, 0, w, x, out, st, nkb, ld, nct);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(2 * grid); hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
@@ -70,12 +70,33 @@ void run(const char* name, float* w, float* x, float* out, unsigned long long* s
 int main() {
     const int ld = 17024, rows = 2048, nkb = 128;
     float *w, *x, *out; unsigned long long* st;
-    hipMalloc(&w, (size_t)(nkb + 2) * 1024 * 4); hipMalloc(&x, (size_t)rows * ld * 4); hipMalloc(&out, 8192 * 64 * 4); hipMalloc(&st, 8192 * 16);
+    hipMalloc(&w, (size_t)(nkb + 2) * 1024 * 4); hipMalloc(&x, (size_t)rows * ld * 4); hipMalloc(&out, 16384 * 64 * 4); hipMalloc(&st, 16384 * 16);
     hipMemset(w, 0, (size_t)(nkb + 2) * 1024 * 4); hipMemset(x, 0, (size_t)rows * ld * 4);
-    for (int grid : {1024, 4096}) {
+    for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {   // random operands: the MFMA datapath toggles, power rises, the effective clock drops
+        std::vector<float> hw((size_t)(nkb + 2) * 1024), hx((size_t)rows * ld);
+        unsigned s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : hw) v = rnd() * 0.1f;
+        for (auto& v : hx) v = rnd();
+        hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        printf("---- random operands ----\n");
+    } else printf("---- all-zero operands ----\n");
+    if (pass == 1) {   // the same loop streaming its B operand from HBM: 2048 distinct column tiles x 1024 rows = 1 GB per launch
+        float* xb; const int ldb = 128 * 2048 + 64;
+        if (hipMalloc(&xb, (size_t)1040 * ldb * 4) == hipSuccess) {
+            hipMemset(xb, 0, (size_t)1040 * ldb * 4);
+            for (size_t r = 0; r < 1040; ++r) hipMemcpy(xb + r * ldb, x, (size_t)std::min(ldb, rows * ld) * 4, hipMemcpyDeviceToDevice);
+            run<1>("B streamed from HBM (1 GB/launch), sched_barrier", w, xb, out, st, nkb, ldb, 16384, 2048);
+            run<1>("B from L2/MALL (same kernel, 64 column tiles)", w, xb, out, st, nkb, ldb, 16384, 64);
+            hipFree(xb);
+        }
+    }
+    for (int grid : {4096, 16384}) {
         run<0>("bare MFMA loop (operands in registers)", w, x, out, st, nkb, ld, grid);
         run<1>("+ 8 dwordx4 loads / 64 MFMAs, sched_barrier", w, x, out, st, nkb, ld, grid);
         run<3>("+ 8 dwordx4 loads / 64 MFMAs, free schedule", w, x, out, st, nkb, ld, grid);
+    }
     }
     return 0;
 }
