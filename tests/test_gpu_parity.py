@@ -250,3 +250,91 @@ def test_gate_activation_accuracy():
     ref = (torch.tanh(x.double()) * torch.sigmoid(x.double()))
     err = float((s.cpu().double() - ref).abs().max())
     assert err < 3e-7, err
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# seeded fuzz: many small awkward shapes (1..8 taps, dilation beyond the sequence, 1..70 channels, 1..300 steps)
+# ---------------------------------------------------------------------------------------------------------------
+def _fuzz_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    for _ in range(n):
+        k = rng.choice([1, 2, 2, 2, 3, 4, 5, 8])
+        d = rng.choice([1, 2, 3, 7, 16, 64, 300, 512])
+        ci, co = rng.choice([1, 3, 8, 9, 31, 32, 40, 64, 70]), rng.choice([1, 2, 8, 15, 32, 33, 64, 70])
+        L = rng.choice([1, 2, 5, 31, 32, 127, 128, 129, 200, 300])
+        cases.append((ci, co, k, d, rng.random() < 0.5, L, rng.choice([1, 2, 3])))
+    return cases
+
+
+def test_block_fuzz_vs_oracle():
+    worst = (0.0, None)
+    for i, (ci, co, k, d, causal, L, B) in enumerate(_fuzz_cases(40, 2024)):
+        torch.manual_seed(1000 + i)
+        blk = _mods().ResidualBlock(ci, co, k, d, causal=causal)
+        with torch.no_grad():
+            for p in blk.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape))
+        sdl = {kk: v.clone().requires_grad_(True) for kk, v in blk.state_dict().items()}
+        x, cr, cs = torch.randn(B, ci, L), torch.randn(B, co, L), torch.randn(B, co, L)
+        xo = x.clone().requires_grad_(True)
+        r0, s0 = O.residual_block(xo, sdl, d, causal)
+        ((r0 * cr).sum() + (s0 * cs).sum()).backward()
+        blk = blk.to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        r1, s1 = blk(xg)
+        ((r1 * cr.to(DEV)).sum() + (s1 * cs.to(DEV)).sum()).backward()
+        errs = {"r": O.rel_err(r1.detach().cpu(), r0), "s": O.rel_err(s1.detach().cpu(), s0),
+                "dx": O.rel_err(xg.grad.cpu(), xo.grad)}
+        for kk, p in blk.named_parameters():
+            ref = sdl[kk].grad
+            if float(ref.abs().max()) == 0.0:      # e.g. a tap that only ever sees the zero padding
+                assert float(p.grad.abs().max()) == 0.0, ((ci, co, k, d, causal, L, B), kk)
+                continue
+            errs[kk] = O.rel_err(p.grad.cpu(), ref)
+        for name, e in errs.items():
+            assert e < TOL, ((ci, co, k, d, causal, L, B), name, e)
+            if e > worst[0]:
+                worst = (e, ((ci, co, k, d, causal, L, B), name))
+    print("worst fuzz error", worst)
+
+
+def test_stack_fuzz_vs_oracle():
+    """Short stacks of blocks with changing widths / taps / dilations plus bottlenecks (the run_stack entry point)."""
+    import random
+    from wavenet_speech_amd.modules.block import run_stack
+    rng = random.Random(77)
+    for i in range(12):
+        torch.manual_seed(500 + i)
+        causal = rng.random() < 0.5
+        widths = [rng.choice([5, 8, 24, 40]) for _ in range(rng.choice([2, 3, 4]) + 1)]
+        out_dim = rng.choice([3, 8, 20])
+        L, B = rng.choice([7, 64, 130, 257]), rng.choice([1, 2])
+        layers = [(widths[j], widths[j + 1], rng.choice([2, 2, 3]), rng.choice([1, 2, 4, 9, 200])) for j in range(len(widths) - 1)]
+        blocks = torch.nn.ModuleList([_mods().ResidualBlock(ci, co, k, d, causal=causal) for ci, co, k, d in layers])
+        botts = torch.nn.ModuleList([torch.nn.Conv1d(co, out_dim, 1) for _ci, co, _k, _d in layers])
+        sd = {}
+        for j, (b, t) in enumerate(zip(blocks, botts)):
+            sd.update({"convolutions.%d.%s" % (j, n): v.clone().requires_grad_(True) for n, v in b.state_dict().items()})
+            sd.update({"bottlenecks.%d.%s" % (j, n): v.clone().requires_grad_(True) for n, v in t.state_dict().items()})
+        x, cot = torch.randn(B, widths[0], L), torch.randn(B, out_dim, L)
+        xo = x.clone().requires_grad_(True)
+        _, S0 = O.block_stack(xo, torch.zeros(B, out_dim, L), sd, layers, causal)
+        (S0 * cot).sum().backward()
+        blocks, botts = blocks.to(DEV), botts.to(DEV)
+        xg = x.to(DEV).requires_grad_(True)
+        S1 = run_stack(xg, blocks, botts)
+        (S1 * cot.to(DEV)).sum().backward()
+        assert O.rel_err(S1.detach().cpu(), S0) < TOL, (layers, "S")
+        assert O.rel_err(xg.grad.cpu(), xo.grad) < TOL, (layers, "dx")
+        named = [("convolutions.%d.%s" % (j, n), p) for j, b in enumerate(blocks) for n, p in b.named_parameters()]
+        named += [("bottlenecks.%d.%s" % (j, n), p) for j, t in enumerate(botts) for n, p in t.named_parameters()]
+        for key, p in named:
+            ref = sd[key].grad
+            if ref is None or float(ref.abs().max()) == 0.0:   # the last block's residual branch feeds nothing
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (layers, key)
+                continue
+            e = O.rel_err(p.grad.cpu(), ref)
+            assert e < TOL, (layers, key, e)
