@@ -46,7 +46,7 @@ typedef enum wn_status {
     WN_ERR_UNSUPPORTED = -2, /* kernel_width > WN_MAX_TAPS, channels > WN_MAX_CHANNELS, or channels*ld*4 >= 2^32 */
     WN_ERR_NULL = -3,        /* a required pointer is NULL */
     WN_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed (see wn_last_hip_error) */
-    WN_ERR_WORKSPACE = -5    /* workspace smaller than wn_*_workspace_bytes() */
+    WN_ERR_WORKSPACE = -5    /* workspace smaller than wn_*_workspace_bytes(), or not 16-byte aligned */
 } wn_status;
 
 #define WN_MAX_TAPS 8

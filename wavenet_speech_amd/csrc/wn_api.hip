@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -588,7 +589,7 @@ int run_wgrad(const std::vector<PairSpec>& ps, int maxdim, int B, int L, int ld,
         if ((double)cp8(std::max(p.a_rows, p.b_rows)) * (double)ld * 4.0 >= 4294967296.0) return WN_ERR_UNSUPPORTED;
     if (ps.empty()) return WN_OK;
     if (!workspace) return WN_ERR_NULL;
-    if (workspace_bytes < wp.bytes()) return WN_ERR_WORKSPACE;
+    if (workspace_bytes < wp.bytes() || (reinterpret_cast<uintptr_t>(workspace) & 15)) return WN_ERR_WORKSPACE;   // 16-byte aligned
     WgradArgs a;
     std::memset(&a, 0, sizeof(a));
     ReduceArgs r;

@@ -226,27 +226,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     const int p = blockIdx.y;
     const ReduceDst d = a.d[p];
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long mn = (long long)d.M * d.N;
-    if (idx < mn && d.w) {
-        const int m = (int)(idx / d.N), n = (int)(idx - (long long)m * d.N);
+    const int nq = (d.N + 3) >> 2;   // each thread sums four consecutive columns (16-byte loads; the slab is padded to Np)
+    if (idx < (long long)d.M * nq && d.w) {
+        const int m = (int)(idx / nq), n = 4 * (int)(idx - (long long)m * nq);
         const float* src = a.slab + d.slab_off + (long long)m * d.Np + n;
         // fixed summation order (split 0, 1, 2, ...: bitwise reproducible), but eight loads in flight at a time
-        float v = 0.0f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         int s = 0;
-        for (; s + 8 <= a.nsplit; s += 8) {
-            float t[8];
+        for (; s + 24 <= a.nsplit; s += 24) {   // the kernel is a chain of dependent round trips: keep 24 loads in flight
+            f32x4 t[24];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = src[(long long)(s + u) * a.slab_floats];
+            for (int u = 0; u < 24; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(s + u) * a.slab_floats);
+#pragma unroll
+            for (int u = 0; u < 24; ++u) v += t[u];
+        }
+        for (; s + 8 <= a.nsplit; s += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (long long)(s + u) * a.slab_floats);
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += t[u];
         }
-        for (; s < a.nsplit; ++s) v += src[(long long)s * a.slab_floats];
-        d.w[(long long)m * d.sm + (long long)n * d.sn] = v;
+        for (; s < a.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (long long)s * a.slab_floats);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < d.N) d.w[(long long)m * d.sm + (long long)(n + j) * d.sn] = v[j];
     }
     if (idx < d.M && (d.b0 || d.b1)) {
         const float* src = a.rowsum + d.rs_off + idx;
         float v = 0.0f;
-        for (int s = 0; s < a.nsplit; ++s) v += src[(long long)s * a.rs_floats];
+        int s = 0;
+        for (; s + 24 <= a.nsplit; s += 24) {   // same fixed order, 24 loads in flight (a serial chain here was the
+            float t[24];                        // whole kernel's critical path: 72 dependent round trips)
+#pragma unroll
+            for (int u = 0; u < 24; ++u) t[u] = src[(long long)(s + u) * a.rs_floats];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) v += t[u];
+        }
+        for (; s < a.nsplit; ++s) v += src[(long long)s * a.rs_floats];
         if (d.b0) d.b0[idx] = v;
         if (d.b1) d.b1[idx] = v;
     }
@@ -267,7 +284,7 @@ hipError_t launch_wgrad(int WT, const WgradArgs& a, hipStream_t st) {
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t st) {
     long long mx = 1;
     for (int p = 0; p < a.npair; ++p) {
-        const long long mn = (long long)a.d[p].M * a.d[p].N;
+        const long long mn = (long long)a.d[p].M * ((a.d[p].N + 3) / 4);
         if (mn > mx) mx = mn;
         if (a.d[p].M > mx) mx = a.d[p].M;
     }
