@@ -219,6 +219,30 @@ def main():
     if timing:
         HF.profile_enable(False)
         kern = HF.profile_read()
+    # SURVEY.md 8(d) also asks for forward-only and forward+backward (no all-reduce / optimizer) figures: measured after
+    # the timed region with events on the current stream, median over the same number of iterations
+    def median_ms(fn):
+        ts = []
+        for _ in range(max(3, args.steps)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def fwd_only():
+        with torch.no_grad():
+            net(x)
+
+    def fwd_bwd():
+        sync.zero()
+        (net(x) * cot).sum().backward()
+
+    breakdown = {"fwd_only_ms": round(median_ms(fwd_only), 2), "fwd_bwd_ms": round(median_ms(fwd_bwd), 2)}
+    breakdown["fwd_bwd_samples_per_s_per_gpu"] = round(B / (breakdown["fwd_bwd_ms"] * 1e-3), 2)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,7 +308,7 @@ def main():
                    "channels": C, "blocks": nblk, "seq_len": L, "batch_per_gpu": B, "global_batch": B * world,
                    "parallelism": "dp%d" % world, "params": nparams},
         "per_gpu": round(value / world, 3),
-        "roofline": roofline, "roofline_step": roofline_step, "kernels": kernels,
+        "breakdown": breakdown, "roofline": roofline, "roofline_step": roofline_step, "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del net, opt, sync, x, cot
