@@ -242,6 +242,7 @@ def main():
         (net(x) * cot).sum().backward()
 
     breakdown = {"fwd_only_ms": round(median_ms(fwd_only), 2), "fwd_bwd_ms": round(median_ms(fwd_bwd), 2)}
+    breakdown["peak_hbm_gib_allocated"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
     breakdown["fwd_bwd_samples_per_s_per_gpu"] = round(B / (breakdown["fwd_bwd_ms"] * 1e-3), 2)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
