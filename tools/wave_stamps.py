@@ -18,7 +18,7 @@ lib = _lib.load()
 x = torch.randn(B, C, L, device=dev); w = torch.randn(C, C, k, device=dev) * 0.05; b = torch.randn(C, device=dev)
 buf = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
 with torch.no_grad():
-    for _ in range(3):
+    for _ in range(int(os.environ.get("WARM", "3"))):   # WARM=1000 to reach the steady-state clock (DVFS ramps for ~0.1 s)
         HF.dilated_conv(x, w, b, 1, True)
     torch.cuda.synchronize()
     lib.wn_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
@@ -30,11 +30,12 @@ grid = ctypes.c_uint.in_dll(lib, "wn_debug_last_grid").value
 s = buf.cpu().numpy().reshape(-1, 8)[:grid]
 s = s[s[:, 0] != 0]
 t0, t1, t2, t3, r0, r1, hw, xcc = [s[:, i].astype(np.int64) for i in range(8)]
+issued = xcc >> 32; xcc = xcc & 0xffffffff   # cycles from K-loop end to the last epilogue store's issue
 cyc = t3 - t0; ns = (r1 - r0) * 10.0
 clock = cyc.sum() / ns.sum()
 print("waves %d  K-blocks %d" % (len(s), k * C // 8))
 print("in-kernel clock: %.3f GHz" % clock)
-for name, d in (("prologue (entry -> first K-block issue)", t1 - t0), ("K loop", t2 - t1), ("epilogue + store drain", t3 - t2), ("wave total", cyc)):
+for name, d in (("prologue (entry -> first K-block issue)", t1 - t0), ("K loop", t2 - t1), ("epilogue: K-loop end -> last store issued", issued), ("store drain (last issue -> all acknowledged)", t3 - t2 - issued), ("epilogue + store drain", t3 - t2), ("wave total", cyc)):
     print("%-42s median %8.0f cyc (%6.2f us)   p10 %8.0f  p90 %8.0f" % (name, np.median(d), np.median(d) / clock / 1e3, np.percentile(d, 10), np.percentile(d, 90)))
 ideal = (k * C // 8) * 64 * 64
 print("ideal K loop = %d cyc -> K-loop efficiency %.1f%%" % (ideal, 100.0 * ideal / np.median(t2 - t1)))

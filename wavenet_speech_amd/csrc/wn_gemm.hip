@@ -228,12 +228,16 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     struct StampOut {
         unsigned long long* p; unsigned long long t0, r0, t1, t2; int lane;
         __device__ ~StampOut() {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t_issued = __builtin_amdgcn_s_memtime();   // every epilogue store has been issued
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // include the drain of the epilogue's stores
             if (p && lane == 0) {
                 p[0] = t0; p[1] = t1; p[2] = t2; p[3] = __builtin_amdgcn_s_memtime();
                 p[4] = r0; p[5] = __builtin_amdgcn_s_memrealtime();
                 p[6] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
-                p[7] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+                // HW_REG_XCC_ID in the low half, cycles from the end of the K loop to the last store's issue in the high half
+                p[7] = (unsigned long long)__builtin_amdgcn_s_getreg(63508) | ((t_issued - t2) << 32);
             }
         }
     } stamp_out{a.stamps ? a.stamps + 8ull * blockIdx.x : nullptr, st_t0, st_r0, st_t1, st_t2, lane};
