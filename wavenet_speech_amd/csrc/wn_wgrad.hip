@@ -27,7 +27,9 @@ constexpr int kPitch = 36;   // LDS row pitch in floats (32 + 4: 16-byte aligned
 
 __device__ __forceinline__ int rowof_w(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int WT>
+// RAGGED = some pair's row count is not a multiple of the workgroup tile: only then are out-of-range staging rows
+// replaced by zeros (4 v_cndmask per staged float4; 65 of the ~150 vector instructions of a chunk).
+template <int WT, bool RAGGED>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int ROWS = 2 * WT * 32;   // rows of the A tile and of the B tile held by the workgroup
     constexpr int PASSES = ROWS / 32;   // staging passes: 32 rows x 32 steps per pass (256 threads x float4)
@@ -78,35 +80,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         offB[q] = (unsigned)(((okB[q] ? br : 0) * ld + 4 * tc) * 4);
     }
     f32x4 ra[PASSES], rb[PASSES];
-    float rs[PASSES];
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) rs[q] = 0.0f;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rs[PASSES];   // row sums of A, kept four-wide (two v_pk_fma per staged float4) and folded once at the end
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) rs[q] = zero4;
 
-    const char* baseA = nullptr;   // wave-uniform byte bases of the chunk being loaded
-    const char* baseB = nullptr;
+    // The chunk being loaded is addressed as buffer resource (SGPRs: the pair's A / B tensor at one utterance) + scalar byte
+    // offset of the chunk's first column + the constant per-thread offset: no vector instruction per load.
+    constexpr unsigned kRsrcFlags = 0x00020000u;   // gfx9 raw buffer, 32-bit data format
+    auto resource = [&](const float* base) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xffffffffu, kRsrcFlags);
+    };
+    __amdgpu_buffer_rsrc_t rsA = resource(pr.A), rsB = resource(pr.Bm);
+    unsigned soA = 0, soB = 0;
     // (utterance, chunk-in-row) of the next chunk to fetch, advanced incrementally (no division in the loop)
     int nb = c_begin / a.chunks_per_row, ncc = c_begin - nb * a.chunks_per_row;
     auto next_chunk = [&](bool advance) {   // branch-free: past the end the last chunk is simply fetched again
-        const long col = (long)a.halo + (long)ncc * kChunk;
-        baseA = reinterpret_cast<const char*>(pr.A + (long)nb * pr.a_cp * ld + col);
-        baseB = reinterpret_cast<const char*>(pr.Bm + (long)nb * pr.b_cp * ld + col + pr.off);
+        const unsigned col = (unsigned)(a.halo + ncc * kChunk);
+        rsA = resource(pr.A + (long)nb * pr.a_cp * ld);
+        rsB = resource(pr.Bm + (long)nb * pr.b_cp * ld);
+        soA = 4u * col;
+        soB = 4u * (unsigned)((int)col + pr.off);   // halo >= |off|: never negative
         const int n1 = ncc + 1;
         const bool wrap = n1 == a.chunks_per_row;
         ncc = advance ? (wrap ? 0 : n1) : ncc;
         nb = advance ? (wrap ? nb + 1 : nb) : nb;
     };
-    auto load_a = [&](int q) { ra[q] = *reinterpret_cast<const f32x4*>(baseA + offA[q]); };
-    auto load_b = [&](int q) { rb[q] = *reinterpret_cast<const f32x4u*>(baseB + offB[q]); };
+    auto load_a = [&](int q) { ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[q], soA, 0)); };
+    auto load_b = [&](int q) { rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[q], soB, 0)); };
+    const bool do_rs = pr.rowsum && tn == 0;   // wave-uniform; the branch below holds no memory instruction
     // registers -> LDS stage st ([row][t], pitch 36), + row sums of A (`real` = 0 for the duplicate chunk that the
     // branch-free tail iteration stages, so that it is not counted twice)
     auto write_a = [&](int st, int q, float real) {
-        const f32x4 v = okA[q] ? ra[q] : zero4;
+        const f32x4 v = (!RAGGED || okA[q]) ? ra[q] : zero4;
         *reinterpret_cast<f32x4*>(&lds[st * STAGE + (q * 32 + trow) * kPitch + 4 * tc]) = v;
-        rs[q] += real * ((v[0] + v[1]) + (v[2] + v[3]));
+        rs[q] += real * v;   // `real` is 0 for the duplicate tail chunk and for workgroups that emit no row sums
     };
     auto write_b = [&](int st, int q) {
-        const f32x4 v = okB[q] ? rb[q] : zero4;
+        const f32x4 v = (!RAGGED || okB[q]) ? rb[q] : zero4;
         *reinterpret_cast<f32x4*>(&lds[st * STAGE + ROWS * kPitch + (q * 32 + trow) * kPitch + 4 * tc]) = v;
     };
 
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) { load_a(q); load_b(q); }
 #pragma unroll
-        for (int q = 0; q < PASSES; ++q) { write_a(0, q, 1.0f); write_b(0, q); }
+        for (int q = 0; q < PASSES; ++q) { write_a(0, q, do_rs ? 1.0f : 0.0f); write_b(0, q); }
         next_chunk(c_begin + 2 < c_end);
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) { load_a(q); load_b(q); }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // Past the last chunk the same chunk is fetched again and written to a stage nobody reads.
     for (int c = c_begin; c < c_end; ++c) {
         const int st = (c - c_begin) & 1;
-        const float real = c + 1 < c_end ? 1.0f : 0.0f;
+        const float real = (c + 1 < c_end && do_rs) ? 1.0f : 0.0f;
         // region 0: registers hold chunk c+1 (loaded during chunk c-1's MFMAs) -> stage st^1
         region(fa0, fb0, [&](int g) {
             if (g & 1) write_b(st ^ 1, g >> 1); else write_a(st ^ 1, g >> 1, real);
@@ -208,11 +219,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             }
 
     // ---- row sums of A (bias gradients): reduce the 8 threads that share a row ------------------
-    if (pr.rowsum && tn == 0) {
+    if (do_rs) {
         float* rsout = a.rowsum + (long long)split * a.rs_floats + pr.rs_off;
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
-            float v = rs[q];
+            float v = (rs[q][0] + rs[q][1]) + (rs[q][2] + rs[q][3]);
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
@@ -272,12 +283,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 hipError_t launch_wgrad(int WT, const WgradArgs& a, hipStream_t st) {
     const unsigned grid = (unsigned)(a.ntile_total * a.nsplit);
     if (grid == 0) return hipSuccess;
+    bool ragged = false;
+    for (int p = 0; p < a.npair; ++p) ragged = ragged || (a.pair[p].a_cp % (64 * WT)) || (a.pair[p].b_cp % (64 * WT));
+#define WN_LAUNCH_WGRAD(W)                                                                              \
+    if (ragged) hipLaunchKernelGGL((wgrad_kernel<W, true>), dim3(grid), dim3(256), 0, st, a);           \
+    else hipLaunchKernelGGL((wgrad_kernel<W, false>), dim3(grid), dim3(256), 0, st, a)
     switch (WT) {
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, dim3(grid), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, dim3(grid), dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(wgrad_kernel<4>, dim3(grid), dim3(256), 0, st, a); break;
+        case 1: WN_LAUNCH_WGRAD(1); break;
+        case 2: WN_LAUNCH_WGRAD(2); break;
+        case 4: WN_LAUNCH_WGRAD(4); break;
         default: return hipErrorInvalidValue;
     }
+#undef WN_LAUNCH_WGRAD
     return hipGetLastError();
 }
 
