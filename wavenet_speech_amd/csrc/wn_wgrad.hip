@@ -19,6 +19,7 @@
 // slabs in a fixed order (deterministic; no float atomics) and scatters into PyTorch layouts.
 // Bias gradients (row sums of A) are accumulated by the staging threads on the fly.
 #include "wn_kernels.h"
+#include <type_traits>
 
 namespace wn {
 
@@ -182,8 +183,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // The loop body is straight-line code (no branches): with control flow around the loads hipcc falls back to
     // s_waitcnt vmcnt(0) before every load and LDS write, which serialises the HBM loads (measured: 2.5 ms vs 1.7 ms).
     // Past the last chunk the same chunk is fetched again and written to a stage nobody reads.
-    for (int c = c_begin; c < c_end; ++c) {
-        const int st = (c - c_begin) & 1;
+    // The LDS stage is a compile-time constant of the body (two chunks per loop iteration), so every LDS address is a
+    // loop-invariant register plus an immediate: a vector instruction in this stream costs ~10 cycles of MFMA issue.
+    auto chunk = [&](auto stage_tag, int c) {
+        constexpr int st = decltype(stage_tag)::value;
         const float real = (c + 1 < c_end && do_rs) ? 1.0f : 0.0f;
         // region 0: registers hold chunk c+1 (loaded during chunk c-1's MFMAs) -> stage st^1
         region(fa0, fb0, [&](int g) {
@@ -203,7 +206,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         region(fa1, fb1, [&](int g) {
             if (g < 2 * WT) load_frag(st ^ 1, 0, g, fa0, fb0);
         });
+    };
+    int c = c_begin;
+    for (; c + 2 <= c_end; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
     }
+    if (c < c_end) chunk(std::integral_constant<int, 0>{}, c);   // c - c_begin is even here
 
     // ---- write the partial tile to this split's slab --------------------------------------------
     float* out = a.slab + (long long)split * a.slab_floats + pr.slab_off;
