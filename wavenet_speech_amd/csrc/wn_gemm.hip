@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     int seg_left = a.seg[0].nkb;
     __amdgpu_buffer_rsrc_t brs = resource(a.seg[0].base + (long)b * a.seg[0].cp * ld);
     unsigned b_soff = 4u * (unsigned)(tilebase + a.seg[0].off);   // halo >= |off|: never negative
-    int a_left = nkb, b_left = nkb;   // k-blocks not yet fetched
+    int b_left = nkb;   // k-blocks not yet fetched
+    const unsigned a_last = (unsigned)(nkb > 0 ? nkb - 1 : 0) * (MT * 1024u);
 
     f32x4 A[2][MT];    // A[slot][m][q]: A operand of k-step q for row-tile m
     breg_t B[4][4];    // B[slot][q][t]: B operand of k-step q for column-tile t
@@ -159,9 +160,7 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             dst[m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, a_off + m * 1024u, a_soff, 0));
-        const int more = min(max(a_left - 1, 0), 1);   // 1 while another k-block follows (pure scalar arithmetic)
-        a_soff += more * (MT * 1024u);
-        a_left -= more;
+        a_soff = min(a_soff + MT * 1024u, a_last);   // stops at the last k-block (s_add + s_min: no vector instruction)
     };
     auto loadB = [&](breg_t (&dst)[4]) {
 #pragma unroll
@@ -169,11 +168,11 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
             if constexpr (NT == 4) dst[q] = __builtin_bit_cast(breg_t, __builtin_amdgcn_raw_buffer_load_b128(brs, b_off[q], b_soff, 0));
             else dst[q] = __builtin_bit_cast(breg_t, __builtin_amdgcn_raw_buffer_load_b64(brs, b_off[q], b_soff, 0));
         }
-        const int more = min(max(b_left - 1, 0), 1);
+        const int more = min(b_left - 1, 1);   // b_left >= 1 always: 1 while another k-block follows, else 0
         b_left -= more;
-        b_soff += more * (32u * (unsigned)ld);
+        b_soff += (unsigned)more * (32u * (unsigned)ld);
         seg_left -= more;
-        if (more != 0 && seg_left == 0) {   // wave-uniform and rare; no vector memory op inside, so the counters stay exact
+        if (b_left > 1 - more && seg_left == 0) {   // (more == 1 && seg_left == 0), written without a bool -> int conversion   // wave-uniform and rare; no vector memory op inside, so the counters stay exact
             ++seg;
             const GemmSeg ns = a.seg[seg];
             seg_left = ns.nkb;
