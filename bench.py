@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq-len", type=int, default=16000)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="skip the extra forward-only / forward+backward runs after the timed region (used when profiling, so "
+                         "that rocprofv3's per-kernel shares are those of the timed steps)")
     return ap.parse_args()
 
 
@@ -241,9 +244,10 @@ def main():
         sync.zero()
         (net(x) * cot).sum().backward()
 
-    breakdown = {"fwd_only_ms": round(median_ms(fwd_only), 2), "fwd_bwd_ms": round(median_ms(fwd_bwd), 2)}
-    breakdown["peak_hbm_gib_allocated"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
-    breakdown["fwd_bwd_samples_per_s_per_gpu"] = round(B / (breakdown["fwd_bwd_ms"] * 1e-3), 2)
+    breakdown = {"peak_hbm_gib_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    if not args.no_breakdown:
+        breakdown.update({"fwd_only_ms": round(median_ms(fwd_only), 2), "fwd_bwd_ms": round(median_ms(fwd_bwd), 2)})
+        breakdown["fwd_bwd_samples_per_s_per_gpu"] = round(B / (breakdown["fwd_bwd_ms"] * 1e-3), 2)
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
