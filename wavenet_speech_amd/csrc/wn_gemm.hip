@@ -45,16 +45,14 @@ __device__ __forceinline__ float tanh_f(float x) {
 
 // B operand of one k-step: NT consecutive time steps of one channel row (one 16- or 8-byte load per lane)
 template <int NT> struct BVec;
-template <> struct BVec<4> { typedef f32x4u load_t; typedef f32x4 reg_t; };
-template <> struct BVec<2> { typedef float __attribute__((ext_vector_type(2), aligned(4))) load_t;
-                             typedef float __attribute__((ext_vector_type(2))) reg_t; };
+template <> struct BVec<4> { typedef f32x4 reg_t; };
+template <> struct BVec<2> { typedef float __attribute__((ext_vector_type(2))) reg_t; };
 
 // MT x NT accumulator tiles per wave (rows x 32*NT time steps); PFB = how many k-blocks ahead the activation
 // (B) operand is prefetched (weights are always one k-block ahead: they are L2 hits); WPS = waves per SIMD the
 // register budget is sized for.
 template <int MT, int NT, int EPI, int PFB, int WPS>
 __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) {
-    typedef typename BVec<NT>::load_t bload_t;
     typedef typename BVec<NT>::reg_t breg_t;
     constexpr int COLS = 32 * NT;
     const int lane = threadIdx.x;

@@ -10,7 +10,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // a float4 that is only guaranteed 4-byte aligned: the dilated taps x[t+off] start at
 // arbitrary columns.  hipcc still emits one global_load_dwordx4 for it on gfx950.
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kMaxSeg = 32;   // K-segments of one GEMM  (>= 1 + 2*WN_MAX_TAPS and >= WN_MAX_STACK_GROUP)
 constexpr int kMaxSlab = 32;  // M-slabs of one GEMM     (WN_MAX_CHANNELS*2 / 64)
