@@ -8,8 +8,8 @@ namespace wn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// a float4 that is only guaranteed 4-byte aligned: the dilated taps x[t+off] start at
-// arbitrary columns.  hipcc still emits one global_load_dwordx4 for it on gfx950.
+// (the dilated taps x[t+off] start at arbitrary, only 4-byte aligned columns: the kernels fetch them with 16-byte
+// buffer loads, which need dword alignment only)
 
 constexpr int kMaxSeg = 32;   // K-segments of one GEMM  (>= 1 + 2*WN_MAX_TAPS and >= WN_MAX_STACK_GROUP)
 constexpr int kMaxSlab = 32;  // M-slabs of one GEMM     (WN_MAX_CHANNELS*2 / 64)
