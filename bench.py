@@ -4,34 +4,54 @@ bench.py -- headline benchmark of BASELINE.json: samples/sec, forward+backward, 
 30-block (3 cycles of dilation 1..512) WaveNet at 16k-sample sequences, batch 16 per GPU
 (BASELINE.json configs[2]; configs[3] = the same with N GPUs, weak scaling, global batch 16*N).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2|cfg5] [--precision f32|f16x3|f16|bf16]
+
+N > 1 without a launcher: bench.py starts the N ranks itself (a child `python -m torch.distributed.run`, one rank
+per GPU over RCCL) BEFORE anything touches the GPU, relays rank 0's JSON line and the child's exit code.  Under an
+external launcher (RANK / WORLD_SIZE in the environment) WORLD_SIZE must equal --gpus.  Fewer visible devices than
+--gpus is an error (exit code 3) -- there is no silent fall-back to fewer GPUs.
 
 A "step" = zero grads, forward, backward of the cotangent loss sum(out*cot), [gradient all-reduce over RCCL],
-Adam update -- nothing is skipped inside the timed region.  Inputs are synthetic fixed-length one-hot
-mu-law waveforms resident in HBM before timing starts; weights are random-init (reference init rules).
+Adam update -- nothing is skipped inside the timed region.  Inputs are synthetic fixed-length waveforms resident in
+HBM before timing starts; weights are random-init (reference init rules).
 
 Prints ONE JSON line (rank 0).  Besides the contract's keys it carries
   roofline      -- dominant kernel, achieved algorithmic TFLOP/s from HIP-event timing on the launch stream
-                   against the dense fp32 MFMA peak (the path is MFMA-bound)
+                   against the dense MFMA peak of the arithmetic used (the path is MFMA-bound)
   roofline_step -- whole-step algorithmic FLOP/s and HBM-byte fractions (both named by north_star)
   kernels       -- per-kernel-class time / launches / achieved TFLOP/s
+  ranks         -- rccl_ranks (dist.get_world_size()), per-rank ms/step, gradient all-reduce ms/step (HIP events)
   cpu_baseline  -- the CPU oracle (same ATen conv1d ops the reference calls) timed on this box's host cores
                    on a bounded sample of the same workload (rank 0, N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense v_mfma_f32_32x32x2_f32 peak
+PEAK_HALF_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA peak (the 5 PF headline figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak
+PROFILE_ROUND = "r02"
+
+# BASELINE.json configs -> workloads.  cfg3 is the configuration the metric is quoted on; the others are parity-test
+# cases that can be timed with the same harness (their lines are committed under profiles/, they are not the headline).
+CONFIGS = {
+    "cfg3": dict(model="wavenet", channels=256, cycles=3, seq_len=16000, batch=16, precision="f32",
+                 label="BASELINE.json configs[2]: WaveNet 256 ch, 30 blocks (3 x dilation 1..512), k=2"),
+    "cfg2": dict(model="rawctcnet", channels=128, cycles=1, seq_len=4096, batch=32, precision="bf16",
+                 label="BASELINE.json configs[1]: RawCTCNet 128 ch, 10 blocks (dilation 1..512) + input block, "
+                       "feature conv k=3, 5 labels, non-causal"),
+    "cfg5": dict(model="wavenet", channels=512, cycles=6, seq_len=48000, batch=2, precision="f16",
+                 label="BASELINE.json configs[4] shape on ONE GPU: WaveNet 512 ch, 60 blocks (6 x dilation 1..512), k=2"),
+}
 
 
 def parse():
@@ -39,17 +59,32 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--channels", type=int, default=256)
-    ap.add_argument("--cycles", type=int, default=3)
-    ap.add_argument("--seq-len", type=int, default=16000)
-    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS),
+                    help="cfg3 = BASELINE configs[2] (the metric's config, default); cfg2 = configs[1] (RawCTCNet 128 ch); "
+                         "cfg5 = configs[4]'s shape on one GPU (512 ch x 60 blocks x 48000)")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16", "bf16"],
+                    help="arithmetic of the block stack; default: the config's (cfg3: f32)")
+    ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--cycles", type=int, default=None)
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU")
+    ap.add_argument("--levels-input", action="store_true",
+                    help="WaveNet only: feed the quantised levels [B, L] to the entry conv as an embedding gather "
+                         "(WaveNet.forward_levels) instead of a dense one-hot [B, 256, L]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seq-len", type=int, default=16000)
+    ap.add_argument("--cpu-seq-len", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true",
                     help="skip the extra forward-only / forward+backward runs after the timed region (used when profiling, so "
                          "that rocprofv3's per-kernel shares are those of the timed steps)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for k in ("channels", "cycles", "seq_len", "batch", "precision"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    if args.cpu_seq_len is None:
+        args.cpu_seq_len = args.seq_len
+    return args
 
 
 def make_layers(channels, cycles):
@@ -58,6 +93,11 @@ def make_layers(channels, cycles):
 
 def log(msg):
     print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def die(code, msg):
+    print("bench.py: ERROR: " + msg, file=sys.stderr, flush=True)
+    sys.exit(code)
 
 
 def host_cores():
@@ -77,26 +117,74 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(channels, cycles, seq_len, budget_s=12.0):
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-GPU launch
+# ----------------------------------------------------------------------------------------------------------------------
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count()   # counts devices without creating a HIP context
+
+
+def self_launch(args):
+    """--gpus N > 1 with no launcher around us: become the launcher.  Nothing has touched the GPU yet (the ranks are
+    fresh child processes; this process never initialises HIP)."""
+    n = visible_gpus()
+    if n < args.gpus:
+        die(3, "--gpus %d requested but only %d GPU(s) are visible; refusing to run on fewer" % (args.gpus, n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env["WN_BENCH_SELF_LAUNCHED"] = "1"
+    log("self-launch: " + " ".join(cmd))
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in child.stdout.splitlines() if l.strip().startswith("{")]
+    if child.returncode != 0 or not lines:
+        sys.stderr.write(child.stdout)
+        die(child.returncode or 4, "the %d-rank child run failed (rc %d, %d JSON lines)" % (args.gpus, child.returncode, len(lines)))
+    print(lines[-1], flush=True)
+    sys.exit(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, budget_s=12.0):
     """Oracle (reference-equivalent ATen CPU ops) fwd+bwd at batch 1 on a bounded sample of the workload:
     the full block stack at a sequence length chosen so one iteration takes ~budget_s; cost is linear in L,
-    so samples/s of the full 16k-step utterance = (L_sample / seq_len) / t."""
+    so samples/s of the full utterance = (L_sample / seq_len) / t."""
+    import torch
     from oracle import wavenet_oracle as O
+    channels, cycles, seq_len = args.channels, args.cycles, args.cpu_seq_len
     layers = make_layers(channels, cycles)
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    sd = O.random_wavenet_state(channels, 2, layers, channels, seed=0)
-    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
     g = torch.Generator().manual_seed(1234)
+    if args.model == "rawctcnet":
+        sd = O.random_rawctcnet_state(channels, 3, 5, layers, channels, seed=0)
+    else:
+        sd = O.random_wavenet_state(channels, 2, layers, channels, seed=0)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
 
     def run(L):
-        q = torch.randint(0, channels, (1, L), generator=g)
-        x = O.one_hot_encoding(q, channels)
-        cot = torch.randn(1, channels, L, generator=g)
+        if args.model == "rawctcnet":
+            x = torch.randn(1, 1, L, generator=g)
+            cot = torch.randn(1, 5, L + 2, generator=g)
+        else:
+            q = torch.randint(0, channels, (1, L), generator=g)
+            x = O.one_hot_encoding(q, channels)
+            cot = torch.randn(1, channels, L, generator=g)
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
-        y = O.wavenet(x, sd, layers, False, impl="aten")
+        if args.model == "rawctcnet":
+            y = O.raw_ctcnet(x, sd, layers, 3, 1, False, False, False, impl="aten")
+        else:
+            y = O.wavenet(x, sd, layers, False, impl="aten")
         (y * cot).sum().backward()
         return time.perf_counter() - t0
 
@@ -106,14 +194,14 @@ def cpu_baseline(channels, cycles, seq_len, budget_s=12.0):
     log("cpu baseline probe: %d steps in %.2f s on %d threads" % (probe_len, t_probe, ncores))
     L_s = int(min(seq_len, max(probe_len, budget_s / (t_probe / probe_len))))
     times = []
-    for _ in range(4):
+    for _ in range(4 if L_s * t_probe / probe_len > 2.0 else 6):
         times.append(run(L_s))
         log("cpu baseline: %d steps in %.2f s" % (L_s, times[-1]))
     best = min(times)
     return {"value": (L_s / float(seq_len)) / best, "unit": "samples/s", "cores": ncores, "kind": "port",
-            "sample": "oracle (ATen conv1d/einsum, fp32, torch %s) fwd+bwd, batch 1, %d ch x %d blocks, %d of %d time "
-                      "steps per iteration (cost linear in L), best of 4 timed iterations after warm-up: %.2f s"
-                      % (torch.__version__, channels, len(layers), L_s, seq_len, best)}
+            "sample": "oracle (ATen conv1d/einsum, fp32, torch %s) fwd+bwd, batch 1, %s %d ch x %d blocks, %d of %d time "
+                      "steps per iteration (cost linear in L), best of %d timed iterations after warm-up: %.2f s"
+                      % (torch.__version__, args.model, channels, len(layers), L_s, seq_len, len(times), best)}
 
 
 # timing classes of the library (wn_prof_*) -> the code-object symbol rocprofv3 reports them under.  The four block GEMMs
@@ -123,77 +211,139 @@ SYMBOL_OF = {
     "series_gemm_kernel<res>": "linear", "series_gemm_kernel<dx>": "linear", "series_gemm_kernel<conv_fwd>": "linear",
     "series_gemm_kernel<conv_bwd_data>": "linear", "series_gemm_kernel<skips_sum>": "linear",
     "series_gemm_kernel<gate>": "gate", "series_gemm_kernel<dz,dgate>": "dgate", "wgrad_kernel": "wgrad",
+    "hgemm_kernel<gate>": "hgate", "hgemm_kernel<res>": "hlinear", "hgemm_kernel<dz,dgate>": "hdgate",
+    "hgemm_kernel<dx>": "hlinear", "hgemm_kernel<skips_sum>": "hlinear", "hwgrad_kernel": "hwgrad",
 }
 SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm_kernel<\d+, \d+, 1,",
-             "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"wgrad_kernel<"}
+             "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"wgrad_kernel<",
+             "hlinear": r"hgemm_kernel<.*EPI=0", "hgate": r"hgemm_kernel<.*EPI=1", "hdgate": r"hgemm_kernel<.*EPI=2",
+             "hwgrad": r"hwgrad_kernel<"}
 SYMBOL_NAME = {"linear": "series_gemm_kernel<4, 4, 0, 3, 1>  [EPI_LINEAR: res, dx, skips_sum, conv launches]",
                "gate": "series_gemm_kernel<4, 4, 1, 3, 1>  [EPI_GATE]", "dgate": "series_gemm_kernel<4, 4, 2, 3, 1>  [EPI_DGATE: dz]",
-               "wgrad": "wgrad_kernel<4>"}
+               "wgrad": "wgrad_kernel<4>", "hlinear": "hgemm_kernel [EPI_LINEAR: res, dx, skips_sum]",
+               "hgate": "hgemm_kernel [EPI_GATE]", "hdgate": "hgemm_kernel [EPI_DGATE: dz]", "hwgrad": "hwgrad_kernel"}
+
+
+def pmc_table(name):
+    import csv
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
+    if not os.path.exists(path):
+        return None, None
+    return list(csv.DictReader(open(path))), os.path.relpath(path, ROOT)
 
 
 def pmc_traffic(symbol):
     """HBM bytes per launch of a kernel symbol from the committed PMC summary (None if absent)."""
-    import csv
     import re
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.csv")
-    if symbol not in SYMBOL_RE or not os.path.exists(path):
-        return None
+    rows, path = pmc_table("pmc_hbm_traffic.csv")
+    if symbol not in SYMBOL_RE or not rows:
+        return None, None
     total = 0.0
-    for row in csv.DictReader(open(path)):
+    for row in rows:
         if re.search(SYMBOL_RE[symbol], row["kernel"]):
             total += float(row["avg_bytes_corrected"])
-    return total or None
+    return (total or None), path
+
+
+def pmc_mfma_busy(symbol):
+    """MFMA-busy fraction of a kernel symbol from the committed PMC summary (None if absent)."""
+    import re
+    rows, path = pmc_table("pmc_mfma.csv")
+    if symbol not in SYMBOL_RE or not rows:
+        return None, None
+    for row in rows:
+        if re.search(SYMBOL_RE[symbol], row["kernel"]):
+            return float(row["mfma_busy_frac"]), path
+    return None, path
 
 
 def main():
     args = parse()
+    args.model = CONFIGS[args.config]["model"]
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        die(2, "--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        self_launch(args)                     # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if world != args.gpus:
+        die(2, "--gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     # RCCL / MIOpen print banners on stdout; the contract is ONE JSON line there.  Send fd 1 to stderr for the run
     # and restore it only to print the result.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    # under torch.distributed.run (RANK set) the RCCL group is always created, even for one rank, so the same
-    # code path (init, barrier, flat-gradient all-reduce, MAX over ranks) runs at N=1 and N=8
-    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    import torch
     import torch.distributed as dist
+    ndev = visible_gpus()
+    if ndev <= local_rank or ndev < 1:
+        die(3, "rank %d needs GPU %d but %d GPU(s) are visible (the HIP path has no CPU fallback)" % (rank, local_rank, ndev))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        die(3, "bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # under torch.distributed.run the RCCL group is always created, even for one rank, so the same code path
+    # (init, barrier, flat-gradient all-reduce, MAX over ranks) runs at N=1 and N=8
+    distributed = launched and "MASTER_PORT" in os.environ
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            die(2, "RCCL group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
+    import wavenet_speech_amd as W
     from wavenet_speech_amd import functional as HF
-    from wavenet_speech_amd.modules.wavenet import WaveNet
     from wavenet_speech_amd.parallel import FlatGradAllReduce
 
     C, L, B = args.channels, args.seq_len, args.batch
     layers = make_layers(C, args.cycles)
     torch.manual_seed(0)  # identical replicas
-    net = WaveNet(C, 2, layers, C, softmax=False).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # each rank its own shard of the global batch
+    levels = None
+    if args.model == "rawctcnet":
+        from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+        net = RawCTCNet(C, 3, 5, layers, C, softmax=False, causal=False).to(dev)
+        x = torch.randn(B, 1, L, generator=g).to(dev)
+        cot = torch.randn(B, 5, L + 2, generator=g).to(dev)
+        nblk = len(layers) + 1
+    else:
+        from wavenet_speech_amd.modules.wavenet import WaveNet
+        net = WaveNet(C, 2, layers, C, softmax=False).to(dev)
+        q = torch.randint(0, C, (B, L), generator=g)
+        if args.levels_input:
+            levels = q.to(dev)
+            x = None
+        else:
+            x = torch.zeros(B, C, L, device=dev).scatter_(1, q.to(dev).unsqueeze(1), 1.0)
+        cot = torch.randn(B, C, L, generator=g).to(dev)
+        nblk = len(layers)
+    W.set_precision(net, args.precision)
     nparams = sum(p.numel() for p in net.parameters())
     try:
         opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)   # same update rule, one multi-tensor kernel
     except (TypeError, RuntimeError):
         opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     sync = FlatGradAllReduce(net.parameters())
+    ar_events = []
 
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # each rank its own shard of the global batch
-    q = torch.randint(0, C, (B, L), generator=g)
-    x = torch.zeros(B, C, L, device=dev).scatter_(1, q.to(dev).unsqueeze(1), 1.0)
-    cot = torch.randn(B, C, L, generator=g).to(dev)
+    def forward():
+        return net.forward_levels(levels) if levels is not None else net(x)
 
-    def step():
+    def step(timed=False):
         sync.zero()
-        out = net(x)
+        out = forward()
         (out * cot).sum().backward()
-        sync.reduce()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sync.reduce()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            sync.reduce()
         opt.step()
 
     def fence():
@@ -202,7 +352,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("model built: %d params; warm-up" % nparams)
+    log("model built: %s, %d params, precision %s; warm-up" % (args.model, nparams, args.precision))
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -214,14 +364,17 @@ def main():
         HF.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     log("timed %d steps: %.1f ms/step" % (args.steps, elapsed / args.steps * 1e3))
     kern = {}
     if timing:
         HF.profile_enable(False)
         kern = HF.profile_read()
+    allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
+
     # SURVEY.md 8(d) also asks for forward-only and forward+backward (no all-reduce / optimizer) figures: measured after
     # the timed region with events on the current stream, median over the same number of iterations
     def median_ms(fn):
@@ -238,29 +391,40 @@ def main():
 
     def fwd_only():
         with torch.no_grad():
-            net(x)
+            forward()
 
     def fwd_bwd():
         sync.zero()
-        (net(x) * cot).sum().backward()
+        (forward() * cot).sum().backward()
 
     breakdown = {"peak_hbm_gib_allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     if not args.no_breakdown:
         breakdown.update({"fwd_only_ms": round(median_ms(fwd_only), 2), "fwd_bwd_ms": round(median_ms(fwd_bwd), 2)})
         breakdown["fwd_bwd_samples_per_s_per_gpu"] = round(B / (breakdown["fwd_bwd_ms"] * 1e-3), 2)
+    per_rank_ms = [round(own_elapsed / args.steps * 1e3, 2)]
+    per_rank_ar = [round(allreduce_ms, 3)]
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, allreduce_ms], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(e[0]), 2) for e in every]
+        per_rank_ar = [round(float(e[1]), 3) for e in every]
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
     # ---- roofline ------------------------------------------------------------------------------------------
-    nblk = len(layers)
-    units = float(B) * L * nblk                        # (b, t, block) units per step per GPU
+    half = args.precision != "f32"
+    nprod = 3 if args.precision == "f16x3" else 1          # MFMA products executed per algorithmic product
+    peak = PEAK_HALF_MFMA_TFLOPS if half else PEAK_FP32_MFMA_TFLOPS
+    esz = 2 if args.precision in ("f16", "bf16") else 4     # bytes per stored activation element
+    L_eff = L + 2 if args.model == "rawctcnet" else L
+    units = float(B) * L_eff * nblk                    # (b, t, block) units per step per GPU
     alg_flops_step = 48.0 * C * C * units              # 48 C^2 flop per (b,t,block) fwd+bwd
-    alg_bytes_step = 8.0 * C * 4 * units               # 8 C s bytes per (b,t,block)
+    alg_bytes_step = 8.0 * C * esz * units             # 8 C s bytes per (b,t,block)
     step_s = elapsed / args.steps
     kernels = {}
     by_symbol = {}
@@ -279,46 +443,65 @@ def main():
         # the dominant kernel = the symbol with the largest share of the timed region (what rocprofv3 --stats ranks first)
         dom = max(by_symbol, key=lambda k: by_symbol[k][0])
         ms, n, fl = by_symbol[dom]
-        ach = fl / (ms * 1e-3) / 1e12
+        ach = nprod * fl / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
+        busy, busy_src = pmc_mfma_busy(dom)
         roofline = {"kernel": SYMBOL_NAME[dom] if C > 64 else dom, "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": pmc_traffic(dom),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
-                                    "separate passes, from profiles/r01/pmc_hbm_traffic.csv (not collected live)",
+                                    "separate passes, from %s (committed summary of tools/collect_profiles.sh at the default "
+                                    "configuration, not collected live)" % traffic_src,
+                    "mfma_busy_frac": busy, "mfma_busy_src": busy_src,
                     "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": fl / n,
+                    "mfma_products_per_algorithmic_product": nprod,
                     "share_of_step": round(ms / args.steps / (step_s * 1e3), 4),
                     "other_symbols": {SYMBOL_NAME[k] if C > 64 else k:
-                                      {"avg_launch_ms": round(v[0] / v[1], 4), "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 2),
-                                       "frac": round(v[2] / (v[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      {"avg_launch_ms": round(v[0] / v[1], 4),
+                                       "tflops": round(nprod * v[2] / (v[0] * 1e-3) / 1e12, 2),
+                                       "frac": round(nprod * v[2] / (v[0] * 1e-3) / 1e12 / peak, 4),
                                        "share_of_step": round(v[0] / args.steps / (step_s * 1e3), 4)}
                                       for k, v in by_symbol.items() if k != dom}}
     kernel_ms = sum(v[0] for v in kern.values())
     roofline_step = {
         "algorithmic_tflops": round(alg_flops_step / step_s / 1e12, 2),
-        "mfma_frac": round(alg_flops_step / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        "mfma_frac": round(nprod * alg_flops_step / step_s / 1e12 / peak, 4),
         "algorithmic_hbm_gbs": round(alg_bytes_step / step_s / 1e9, 1),
         "hbm_frac": round(alg_bytes_step / step_s / 1e9 / PEAK_HBM_GBS, 4),
         "hip_kernel_ms_per_step": round(kernel_ms / args.steps, 2) if kern else None,
-        "accounting": "48*C^2 flop and 8*C*4 B per (utterance, time step, block), SURVEY.md 8(d)",
+        "accounting": "48*C^2 flop and 8*C*%d B per (utterance, time step, block), SURVEY.md 8(d); mfma_frac counts %d MFMA "
+                      "product(s) per algorithmic product against the %.1f TFLOP/s dense peak" % (esz, nprod, peak),
     }
 
+    dtype = {"f32": "f32", "f16x3": "f16x3 (3-product fp16 split, fp32 accumulate, fp32-equivalent results)",
+             "f16": "f16", "bf16": "bf16"}[args.precision]
+    headline = args.config == "cfg3" and (C, args.cycles, L, B) == tuple(CONFIGS["cfg3"][k] for k in
+                                                                         ("channels", "cycles", "seq_len", "batch"))
+    metric = ("samples/sec fwd+bwd, 256-ch 30-block WaveNet @16k seq" if headline else
+              "samples/sec fwd+bwd, %d-ch %d-block %s @%d seq" % (C, nblk, args.model, L))
     result = {
-        "metric": "samples/sec fwd+bwd, 256-ch 30-block WaveNet @16k seq",
+        "metric": metric,
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: WaveNet %d ch, %d blocks (%d x dilation 1..512), k=2, "
-                               "seq_len %d, batch %d per GPU, fp32, full step (fwd+bwd+grad all-reduce+Adam)"
-                               % (C, nblk, args.cycles, L, B),
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "%s, seq_len %d, batch %d per GPU, %s, full step (fwd+bwd+grad all-reduce+Adam)"
+                               % (CONFIGS[args.config]["label"] if headline or args.config != "cfg3" else
+                                  "WaveNet %d ch, %d blocks" % (C, nblk), L, B, args.precision),
                    "channels": C, "blocks": nblk, "seq_len": L, "batch_per_gpu": B, "global_batch": B * world,
-                   "parallelism": "dp%d" % world, "params": nparams},
+                   "parallelism": "dp%d" % world, "params": nparams,
+                   "input": "levels (embedding gather)" if levels is not None else
+                            ("raw signal" if args.model == "rawctcnet" else "dense one-hot")},
         "per_gpu": round(value / world, 3),
+        "ranks": {"rccl_ranks": dist.get_world_size() if distributed else 0,
+                  "launcher": "self" if os.environ.get("WN_BENCH_SELF_LAUNCHED") else ("external" if launched else "none"),
+                  "ms_per_step_by_rank": per_rank_ms, "grad_allreduce_ms_by_rank": per_rank_ar,
+                  "grad_allreduce_payload_mb": round(sync.payload_bytes() / 1e6, 1)},
         "breakdown": breakdown, "roofline": roofline, "roofline_step": roofline_step, "kernels": kernels,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del net, opt, sync, x, cot
         torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(C, args.cycles, args.cpu_seq_len)
+        result["cpu_baseline"] = cpu_baseline(args)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define WN_VERSION 100 /* 0.1.0 */
+#define WN_VERSION 200 /* 0.2.0 */
 
 typedef void* wn_stream_t; /* hipStream_t */
 
@@ -146,7 +146,9 @@ int wn_block_backward_data(const wn_block_shape* s, const void* packed,
  *   dW_tanh[:,:,j] = sum da[t] x[t+off_j]^T, dW_sigmoid likewise with dg, dW_res = sum dr z^T,
  *   dW_proj = sum dr x^T, dW_skip = sum dskip z^T, biases = row sums.  Deterministic (split-K
  *   partial slabs reduced in a fixed order).  Gradients are OVERWRITTEN, not accumulated.
- *   dr may be NULL: then dW_res, db_res, dW_proj, db_proj are written as zeros. */
+ *   dr may be NULL (no consumer of the residual output: the last block of a stack).  The four residual-path
+ *   gradient pointers (w_res, b_res, w_proj, b_proj) may then be NULL too -- "no gradient", as autograd leaves
+ *   them in the reference -- and any of them that is given is written as zeros. */
 size_t wn_block_wgrad_workspace_bytes(const wn_block_shape* s);
 int wn_block_backward_weights(const wn_block_shape* s, const float* x, const float* z,
                               const float* da, const float* dg, const float* dr, const float* dskip,
@@ -172,10 +174,12 @@ int wn_conv_backward_weights(const wn_conv_shape* s, const float* x, const float
  * legacy_code/train.py:37-39.  logits: dense [B][C][L] floats; target: [B][L] int64 class indices.
  *   forward : lse[b][t] = logsumexp_c logits[b][c][t];  partial[i] = sum over workgroup i of (lse - logits[target])
  *             (wn_nll_partials(B, L) floats; the caller sums them in order and divides by B: deterministic)
+ *             A target outside [0, C) is never used as an index: it is counted in *bad_targets (one DEVICE int the caller
+ *             zeroed; may be NULL) and makes its workgroup's partial NaN (torch asserts on the device in that case).
  *   backward: dlogits = (exp(logits - lse) - onehot(target)) * gscale[0]      (gscale: one DEVICE float, = dloss / B) */
 size_t wn_nll_partials(int batch, int length);
-int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int batch, int classes,
-                   int length, wn_stream_t stream);
+int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int* bad_targets,
+                   int batch, int classes, int length, wn_stream_t stream);
 int wn_nll_backward(const float* logits, const long long* target, const float* lse, const float* gscale, float* dlogits,
                     int batch, int classes, int length, wn_stream_t stream);
 

@@ -325,3 +325,53 @@ def random_wavenet_state(in_dim, entry_kwidth, layers, out_dim, seed=0, dtype=to
     sd["output_stack.3.weight"] = ku(out_dim, out_dim, 1)
     sd["output_stack.3.bias"] = torch.zeros(out_dim, dtype=dtype)
     return sd
+
+
+def random_rawctcnet_state(num_features, feature_kwidth, num_labels, layers, out_dim, input_kernel_size=2, seed=0,
+                           dtype=torch.float32):
+    """State dict with the key names/shapes of RawCTCNet (modules/raw_ctcnet.py:57-93, positions=False) and values
+    following its init rules (:95-115: kaiming-uniform weights, ~0 biases, identity + 1e-4 noise bottlenecks).
+    Values are NOT bit-identical to the reference initialiser; used by bench.py's cpu_baseline leg."""
+    g = torch.Generator().manual_seed(seed)
+
+    def ku(*shape):
+        fan_in = shape[1] * (shape[2] if len(shape) > 2 else 1)
+        bound = math.sqrt(6.0 / fan_in)
+        return ((torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+
+    def nz(n):
+        return (1e-4 * torch.randn(n, generator=g, dtype=torch.float64)).to(dtype)
+
+    def eye(co, ci):
+        return (torch.eye(co, ci, dtype=torch.float64) + 1e-4 * torch.randn(co, ci, generator=g, dtype=torch.float64)
+                ).to(dtype).unsqueeze(2)
+
+    F_, c0 = num_features, layers[0][0]
+    sd = {"feature_layer.0.weight": ku(F_, 1, feature_kwidth), "feature_layer.0.bias": nz(F_),
+          "feature_layer.2.weight": ku(F_, F_, 1), "feature_layer.2.bias": nz(F_)}
+
+    def block(pre, ci, co, k):
+        sd[pre + "conv_tanh.conv1d.weight"] = ku(co, ci, k)
+        sd[pre + "conv_tanh.conv1d.bias"] = nz(co)
+        sd[pre + "conv_sigmoid.conv1d.weight"] = ku(co, ci, k)
+        sd[pre + "conv_sigmoid.conv1d.bias"] = nz(co)
+        sd[pre + "conv1x1_residual.weight"] = ku(co, co, 1)
+        sd[pre + "conv1x1_residual.bias"] = nz(co)
+        sd[pre + "conv1x1_skip.weight"] = ku(co, co, 1)
+        sd[pre + "conv1x1_skip.bias"] = nz(co)
+        sd[pre + "residual_proj.weight"] = ku(co, ci)
+        sd[pre + "residual_proj.bias"] = nz(co)
+
+    block("input_block.", F_, c0, input_kernel_size)
+    sd["input_skip_bottleneck.weight"] = ku(out_dim, c0, 1)
+    sd["input_skip_bottleneck.bias"] = nz(out_dim)
+    for l, (ci, co, k, _d) in enumerate(layers):
+        block("convolutions.%d." % l, ci, co, k)
+    for l, (_ci, co, _k, _d) in enumerate(layers):
+        sd["bottlenecks.%d.weight" % l] = eye(out_dim, co)
+        sd["bottlenecks.%d.bias" % l] = nz(out_dim)
+    sd["output_block.1.weight"] = ku(out_dim, out_dim, 1)
+    sd["output_block.1.bias"] = nz(out_dim)
+    sd["output_block.3.weight"] = ku(num_labels, out_dim, 1)
+    sd["output_block.3.bias"] = nz(num_labels)
+    return sd

@@ -29,7 +29,7 @@ def _data():
     return torch.randn(6, 6, 40, generator=g), torch.randn(6, 6, 40, generator=g)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, async_op=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +40,12 @@ def _worker(rank, world, port, out):
     b, e = shard_bounds(x.shape[0], rank, world)
     sync.zero()
     _loss(params, x[b:e], cot[b:e]).backward()
-    sync.reduce()
+    if async_op:
+        handle = sync.reduce(async_op=True)      # the handle's wait() must also apply the 1/world average
+        handle.wait()
+        handle.wait()                            # idempotent
+    else:
+        sync.reduce()
     # every gradient is still a view of the flat buffer, and all ranks agree bit for bit
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     flat = sync.flat.clone()
@@ -71,6 +76,18 @@ def test_two_rank_allreduce_matches_single_process(tmp_path):
         if p.grad is None:
             continue
         assert O.rel_err(got[k], p.grad) < 1e-5, k
+
+
+def test_two_rank_async_allreduce_applies_the_average(tmp_path):
+    out = str(tmp_path / "grads_async.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    params = _params()
+    x, cot = _data()
+    _loss(params, x, cot).backward()
+    for k, p in params.items():
+        if p.grad is not None:
+            assert O.rel_err(got[k], p.grad) < 1e-5, k
 
 
 def test_flat_buffer_single_process_semantics():

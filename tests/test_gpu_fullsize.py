@@ -88,8 +88,13 @@ def test_cfg3_reference_init_is_as_close_to_fp64_as_the_cpu_fp32_path():
         y_cpu = O.wavenet(x, sd, layers, False, impl="aten")
         y_hip = net.to(DEV)(x.to(DEV)).cpu()
     e_cpu, e_hip = O.rel_err(y_cpu.double(), y64), O.rel_err(y_hip.double(), y64)
-    print("reference init, 30 blocks: CPU fp32 vs fp64 %.2e, HIP fp32 vs fp64 %.2e" % (e_cpu, e_hip))
+    e_direct = O.rel_err(y_hip, y_cpu)     # the quantity north_star names: HIP vs the CPU fp32 path, same inputs
+    print("reference init, 30 blocks: CPU fp32 vs fp64 %.2e, HIP fp32 vs fp64 %.2e, HIP vs CPU fp32 %.2e"
+          % (e_cpu, e_hip, e_direct))
     assert e_hip < max(TOL, 2.0 * e_cpu)
+    # two fp32 evaluations of this ill-conditioned map (|r| grows ~sqrt(2) per block) cannot agree better than each agrees
+    # with the fp64 truth: the direct difference is bounded by the sum of the two fp64 errors
+    assert e_direct <= 1.05 * (e_cpu + e_hip) + 1e-7
 
 
 def test_cfg3_full_batch_properties():
@@ -145,10 +150,90 @@ def test_cfg2_shape_raw_ctcnet_vs_oracle():
     (y0 * cot).sum().backward()
     assert O.rel_err(y1.detach().cpu(), y0) < TOL
     for k, p in net.named_parameters():
-        if sd[k].grad is None:      # the last block's residual output is unused: autograd gives None, the HIP path zeros
-            assert float(p.grad.abs().max()) == 0.0, k
+        if sd[k].grad is None:      # the last block's residual output is unused: no gradient on either side
+            assert p.grad is None, k
             continue
         assert O.rel_err(p.grad.cpu(), sd[k].grad) < TOL, k
+
+
+def _properties(net, x, cot, prefix, split, causal_prefix):
+    """size-independent properties at a configuration's full size: bitwise determinism of outputs and gradients,
+    [causality: prefix of the output == output of the prefix], batch additivity of the weight gradients,
+    per-utterance independence."""
+    def grads(xs, cs):
+        net.zero_grad(set_to_none=True)
+        y = net(xs)
+        (y * cs).sum().backward()
+        return y.detach(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    y, g_all = grads(x, cot)
+    y2, g_again = grads(x, cot)
+    assert torch.equal(y, y2) and all(torch.equal(g_all[k], g_again[k]) for k in g_all)
+    assert bool(torch.isfinite(y).all()) and all(bool(torch.isfinite(v).all()) for v in g_all.values())
+    if causal_prefix:
+        with torch.no_grad():
+            y_prefix = net(x[:, :, :prefix].contiguous())
+        assert torch.equal(y_prefix, y[:, :, :prefix])
+    _, g_a = grads(x[:split].contiguous(), cot[:split].contiguous())
+    _, g_b = grads(x[split:].contiguous(), cot[split:].contiguous())
+    for k in g_all:
+        assert O.rel_err((g_a[k] + g_b[k]).cpu(), g_all[k].cpu()) < 1e-5, k
+    i = x.shape[0] - 1
+    with torch.no_grad():
+        yi = net(x[i:i + 1].contiguous())
+    assert torch.equal(yi[0], y[i])
+    return y
+
+
+def test_cfg2_full_batch_properties():
+    """BASELINE configs[1] at its stated size: RawCTCNet 128 ch x (10 + input) blocks, L=4096, batch 32 (fp32 here)."""
+    from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+    torch.manual_seed(12)
+    layers = [(128, 128, 2, 2 ** i) for i in range(10)]
+    net = RawCTCNet(128, 3, 5, layers, 128, softmax=False, causal=False).to(DEV)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(32, 1, 4096, generator=g).to(DEV)
+    cot = torch.randn(32, 5, 4098, generator=g).to(DEV)
+    y = _properties(net, x, cot, None, 16, causal_prefix=False)     # non-causal: no prefix property
+    assert tuple(y.shape) == (32, 5, 4098)
+    # one utterance of the batch against the oracle
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        y0 = O.raw_ctcnet(x[7:8].cpu(), sd, layers, 3, 1, False, False, False, impl="aten")
+    assert O.rel_err(y[7:8].cpu(), y0) < TOL
+
+
+def test_cfg5_full_depth_and_length_properties():
+    """BASELINE configs[4]'s shape on one GPU: WaveNet 512 ch x 60 blocks (6 x dilation 1..512) x L=48000, batch 2
+    (fp32 here).  60 blocks = two skips_sum groups: the second one accumulates (EPI_ACCUM)."""
+    c, L, B = 512, 48000, 2
+    layers = _layers(c, 6)
+    net = _wavenet(c, layers, seed=21).to(DEV)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, c, L, generator=g).to(DEV)
+    cot = torch.randn(B, c, L, generator=g).to(DEV)
+    _properties(net, x, cot, 8192, 1, causal_prefix=True)
+
+
+def test_cfg5_full_depth_one_utterance_vs_oracle():
+    """all 60 blocks of configs[4] against the oracle at the longest sequence the CPU finishes in well under a minute"""
+    c, L = 512, 6000
+    layers = _layers(c, 6)
+    net = _wavenet(c, layers, seed=23)
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(24)
+    x, cot = torch.randn(1, c, L, generator=g), torch.randn(1, c, L, generator=g)
+    net = net.to(DEV)
+    slopes, remove = O.capture_leaky_slopes(net)
+    y1 = net(x.to(DEV))
+    remove()
+    (y1 * cot.to(DEV)).sum().backward()
+    y0 = O.wavenet(x, sd, layers, False, impl="aten", slopes=slopes)
+    (y0 * cot).sum().backward()
+    assert O.rel_err(y1.detach().cpu(), y0) < TOL
+    for k, p in net.named_parameters():
+        if sd[k].grad is not None:
+            assert O.rel_err(p.grad.cpu(), sd[k].grad) < TOL, k
 
 
 def test_cfg5_width_512_channels_vs_oracle():

@@ -11,5 +11,6 @@ libwavenet_amd.so (include/wavenet_amd.h).  No CPU fallback exists.
 from . import functional, modules, series  # noqa: F401
 from .modules import (CausalConv1d, NonCausalConv1d, RawCTCNet, ResidualBlock, WaveNet,  # noqa: F401
                       WaveNetClassifier)
+from .modules.block import set_precision  # noqa: F401
 
 __version__ = "0.1.0"

@@ -75,7 +75,7 @@ SIGNATURES = {
     "wn_conv_backward_weights": (c_int, [POINTER(ConvShape), c_float_p, c_float_p, c_float_p, c_float_p,
                                          c_void_p, c_size_t, c_void_p]),
     "wn_nll_partials": (c_size_t, [c_int, c_int]),
-    "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
+    "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
     "wn_prof_enable": (c_int, [c_int]),
     "wn_prof_reset": (c_int, []),
@@ -102,7 +102,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.wn_version() < 100:
+    if lib.wn_version() < 200:
         raise RuntimeError("libwavenet_amd.so too old")
     _lib = lib
     return lib

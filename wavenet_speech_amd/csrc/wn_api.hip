@@ -666,16 +666,18 @@ int wn_block_backward_weights(const wn_block_shape* s, const float* x, const flo
     int rc = check_block(s, off);
     if (rc != WN_OK) return rc;
     if (!x || !z || !da || !dg || !dskip || !grads) return WN_ERR_NULL;
-    if (!grads->w_tanh || !grads->b_tanh || !grads->w_sigmoid || !grads->b_sigmoid || !grads->w_res || !grads->b_res ||
-        !grads->w_skip || !grads->b_skip || !grads->w_proj || !grads->b_proj)
+    if (!grads->w_tanh || !grads->b_tanh || !grads->w_sigmoid || !grads->b_sigmoid || !grads->w_skip || !grads->b_skip)
         return WN_ERR_NULL;
+    // the residual path's four gradients are required only when the block HAS a residual consumer (dr != NULL);
+    // with dr == NULL they may be NULL ("no gradient", what autograd gives the reference's last block) or buffers to zero
+    if (dr && (!grads->w_res || !grads->b_res || !grads->w_proj || !grads->b_proj)) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int Ci = s->in_channels, Co = s->out_channels;
     if (!dr) {
-        WN_HIP(hipMemsetAsync(grads->w_res, 0, (size_t)Co * Co * 4, st), "memset dW_res");
-        WN_HIP(hipMemsetAsync(grads->b_res, 0, (size_t)Co * 4, st), "memset db_res");
-        WN_HIP(hipMemsetAsync(grads->w_proj, 0, (size_t)Co * Ci * 4, st), "memset dW_proj");
-        WN_HIP(hipMemsetAsync(grads->b_proj, 0, (size_t)Co * 4, st), "memset db_proj");
+        if (grads->w_res) WN_HIP(hipMemsetAsync(grads->w_res, 0, (size_t)Co * Co * 4, st), "memset dW_res");
+        if (grads->b_res) WN_HIP(hipMemsetAsync(grads->b_res, 0, (size_t)Co * 4, st), "memset db_res");
+        if (grads->w_proj) WN_HIP(hipMemsetAsync(grads->w_proj, 0, (size_t)Co * Ci * 4, st), "memset dW_proj");
+        if (grads->b_proj) WN_HIP(hipMemsetAsync(grads->b_proj, 0, (size_t)Co * 4, st), "memset db_proj");
     }
     std::vector<PairSpec> ps = block_pairs(s, off, x, z, da, dg, dr, dskip, grads);
     return run_wgrad(ps, std::max(std::max(Ci, Co), s->skip_rows), s->batch, s->length, s->ld, s->halo, workspace,
@@ -838,11 +840,11 @@ size_t wn_nll_partials(int batch, int length) {
     return (size_t)(((long long)batch * ((length + 3) / 4) + 255) / 256);
 }
 
-int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int batch, int classes,
-                   int length, wn_stream_t stream) {
+int wn_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int* bad_targets, int batch,
+                   int classes, int length, wn_stream_t stream) {
     if (batch <= 0 || classes <= 0 || length <= 0) return WN_ERR_BAD_SHAPE;
     if (!logits || !target || !lse || !partial) return WN_ERR_NULL;
-    WN_HIP(launch_nll_forward(logits, target, lse, partial, batch, classes, length, (hipStream_t)stream), "nll_forward");
+    WN_HIP(launch_nll_forward(logits, target, lse, partial, bad_targets, batch, classes, length, (hipStream_t)stream), "nll_forward");
     return WN_OK;
 }
 

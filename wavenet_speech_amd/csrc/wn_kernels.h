@@ -148,8 +148,8 @@ hipError_t launch_gemm(int MT, int epi, const GemmArgs& a, hipStream_t st);
 hipError_t launch_pack(const PackArgs& a, hipStream_t st);
 hipError_t launch_wgrad(int WT, const WgradArgs& a, hipStream_t st);
 hipError_t launch_wgrad_reduce(const ReduceArgs& a, hipStream_t st);
-hipError_t launch_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int B, int C, int L,
-                              hipStream_t st);
+hipError_t launch_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int* bad_targets, int B,
+                              int C, int L, hipStream_t st);
 hipError_t launch_nll_backward(const float* logits, const long long* target, const float* lse, const float* gscale,
                                float* dlogits, int B, int C, int L, hipStream_t st);
 

@@ -12,7 +12,8 @@
 namespace wn {
 
 __global__ __launch_bounds__(256) void nll_forward_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
-                                                          float* __restrict__ lse, float* __restrict__ partial, int B, int C, int L) {
+                                                          float* __restrict__ lse, float* __restrict__ partial,
+                                                          int* __restrict__ bad_targets, int B, int C, int L) {
     const int L4 = (L + 3) / 4;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     float loss = 0.0f;
@@ -46,7 +47,12 @@ __global__ __launch_bounds__(256) void nll_forward_kernel(const float* __restric
             if (t0 + j < L) {
                 const float l = m[j] + __logf(s[j]);
                 lse[(long long)b * L + t0 + j] = l;
-                const long long tg = target[(long long)b * L + t0 + j];
+                long long tg = target[(long long)b * L + t0 + j];
+                if (tg < 0 || tg >= C) {   // never index the logits with an unchecked label: count it, read class 0, poison the loss
+                    if (bad_targets) atomicAdd(bad_targets, 1);
+                    tg = 0;
+                    loss = __builtin_nanf("");
+                }
                 loss += l - logits[((long long)b * C + tg) * L + t0 + j];
             }
         }
@@ -94,9 +100,11 @@ __global__ __launch_bounds__(256) void nll_backward_kernel(const float* __restri
     }
 }
 
-hipError_t launch_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int B, int C, int L, hipStream_t st) {
+hipError_t launch_nll_forward(const float* logits, const long long* target, float* lse, float* partial, int* bad_targets, int B, int C,
+                              int L, hipStream_t st) {
     const long long n = (long long)B * ((L + 3) / 4);
-    hipLaunchKernelGGL(nll_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logits, target, lse, partial, B, C, L);
+    hipLaunchKernelGGL(nll_forward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, logits, target, lse, partial,
+                       bad_targets, B, C, L);
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@ C ABI.  torch supplies device memory, the current HIP stream and autograd bookke
 There is no CPU path: CPU tensors raise.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -113,9 +114,13 @@ def _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dskip, want_dx, 
     _lib.check(lib.wn_block_backward_data(ctypes.byref(shape), _p(packed), _p(dr), _p(dskip), _p(ta), _p(sg),
                                           _p(da), _p(dg), _p(dx), _stream()), "wn_block_backward_data")
     k = spec.k
-    grads = [torch.empty(s, dtype=torch.float32, device=device) for s in
-             [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
-              (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]]
+    shapes = [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
+              (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]
+    # the last block of a stack has no consumer of its residual output (dr is None): conv1x1_residual and
+    # residual_proj then get NO gradient (None), exactly as autograd leaves them in the reference -- a zero tensor
+    # would make weight-decay optimisers decay parameters the reference never touches
+    unused = (4, 5, 8, 9) if dr is None else ()
+    grads = [None if i in unused else torch.empty(s, dtype=torch.float32, device=device) for i, s in enumerate(shapes)]
     ws_bytes = lib.wn_block_wgrad_workspace_bytes(ctypes.byref(shape))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
     gs = _params_struct(grads)
@@ -155,7 +160,7 @@ class _ResidualStackFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, specs, *flat):
+    def forward(ctx, x, specs, grad_enabled, pack_cache, *flat):
         lib = _lib.load()
         _require_device(x, "input")
         n = len(specs)
@@ -163,9 +168,16 @@ class _ResidualStackFn(torch.autograd.Function):
         B, C0, L = x.shape
         if C0 != specs[0].ci:
             raise RuntimeError("wavenet_speech_amd: input has %d channels, first block expects %d" % (C0, specs[0].ci))
+        for l in range(1, n):
+            if specs[l].ci != specs[l - 1].co:   # the reference raises a conv1d shape error here
+                raise RuntimeError("wavenet_speech_amd: block %d expects %d input channels but block %d produces %d"
+                                   % (l, specs[l].ci, l - 1, specs[l - 1].co))
         dev = x.device
         layout = SeriesLayout(L, max(s.reach() for s in specs))
-        training = any(ctx.needs_input_grad)
+        # needs_input_grad reflects requires_grad of the arguments whatever the grad mode, and grad mode is always off
+        # inside Function.forward: the caller captures torch.is_grad_enabled() and hands it in
+        training = bool(grad_enabled) and any(ctx.needs_input_grad)
+        ctx.training = training
         cur = Lease(B, C0, layout, dev)
         load_series(cur.t, x.detach(), layout)
         ms = specs[0].ms
@@ -177,7 +189,12 @@ class _ResidualStackFn(torch.autograd.Function):
                 raise RuntimeError("wavenet_speech_amd: all blocks of a stack must share out_dim")
             shape = _shape(spec, B, layout)
             params = _prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec)
-            packed = _pack_block(lib, shape, params, dev)
+            if pack_cache is not None and not training:
+                packed = pack_cache.get(l, layout, B)
+                if packed is None:
+                    packed = pack_cache.put(l, layout, B, _pack_block(lib, shape, params, dev))
+            else:
+                packed = _pack_block(lib, shape, params, dev)
             r = Lease(B, spec.co, layout, dev) if l + 1 < n else None  # the last residual output is never used
             if training:
                 ta, sg, z = (Lease(B, spec.co, layout, dev) for _ in range(3))
@@ -223,14 +240,46 @@ class _ResidualStackFn(torch.autograd.Function):
             ctx.saved[l] = None  # release this block's activations to the pool
         dx0 = window(dr.t, specs[0].ci, layout).clone() if ctx.needs_input_grad[0] else None
         # 1x1 Conv1d weights come in as [Co][Ci][1]; hand each gradient back in its parameter's own shape
-        grads_flat = [g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
-        return (dx0, None) + tuple(grads_flat)
+        grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
+        return (dx0, None, None, None) + tuple(grads_flat)
 
 
-def residual_stack(x, specs, flat_params):
+class PackCache(object):
+    """Packed (MFMA-fragment order) weights of a stack, kept across forwards for inference: under torch.no_grad() the
+    weights do not change between calls, so re-packing them on every forward is wasted launches.  The owner (a module)
+    calls `validate(params)` before each use; any in-place update (optimizer step, load_state_dict) bumps a parameter's
+    `_version` and empties the cache."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = {}
+        self.hits = 0
+
+    def validate(self, params, extra=()):
+        key = tuple((id(p), p._version, p.device) for p in params) + tuple(extra)
+        if key != self.key:
+            self.key = key
+            self.packed = {}
+
+    def get(self, l, layout, batch):
+        t = self.packed.get((l, layout.key(), batch))
+        if t is not None:
+            self.hits += 1
+        return t
+
+    def put(self, l, layout, batch, t):
+        self.packed[(l, layout.key(), batch)] = t
+        return t
+
+
+def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None):
     """skips_sum of a stack of residual blocks.  flat_params: 10 tensors per block in C-ABI order
-    (w_tanh, b_tanh, w_sigmoid, b_sigmoid, w_res [Co,Co,1], b_res, w_skip [Ms,Co], b_skip, w_proj, b_proj)."""
-    return _ResidualStackFn.apply(x, tuple(specs), *flat_params)
+    (w_tanh, b_tanh, w_sigmoid, b_sigmoid, w_res [Co,Co,1], b_res, w_skip [Ms,Co], b_skip, w_proj, b_proj).
+    precision: "f32" (exact fp32 MFMA, default) or one of the half-precision MFMA modes of functional_half."""
+    if precision != "f32":
+        from . import functional_half
+        return functional_half.residual_stack(x, specs, flat_params, precision)
+    return _ResidualStackFn.apply(x, tuple(specs), torch.is_grad_enabled(), pack_cache, *flat_params)
 
 
 class _ResidualBlockFn(torch.autograd.Function):
@@ -238,7 +287,7 @@ class _ResidualBlockFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, spec, *params):
+    def forward(ctx, x, spec, grad_enabled, *params):
         lib = _lib.load()
         _require_device(x, "input")
         B, C0, L = x.shape
@@ -253,7 +302,7 @@ class _ResidualBlockFn(torch.autograd.Function):
         load_series(xin.t, x.detach(), layout)
         r = Lease(B, spec.co, layout, dev)
         s = Lease(B, spec.ms, layout, dev)
-        training = any(ctx.needs_input_grad)
+        training = bool(grad_enabled) and any(ctx.needs_input_grad)
         ta, sg = (Lease(B, spec.co, layout, dev), Lease(B, spec.co, layout, dev)) if training else (None, None)
         z = Lease(B, spec.co, layout, dev)
         _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(xin), _p(r), _p(s), 0,
@@ -279,12 +328,12 @@ class _ResidualBlockFn(torch.autograd.Function):
         grads = [g.view(shp) for g, shp in zip(grads, ctx.param_shapes)]
         dx0 = _own(dx.view()) if dx is not None else None
         ctx.saved = None
-        return (dx0, None) + tuple(grads)
+        return (dx0, None, None) + tuple(grads)
 
 
 def residual_block(x, spec, params):
     """(residual_out, skip_out) of one block; params in C-ABI order with w_res / w_skip as [Co,Co,1] Conv1d weights."""
-    return _ResidualBlockFn.apply(x, spec, *params)
+    return _ResidualBlockFn.apply(x, spec, torch.is_grad_enabled(), *params)
 
 
 class _DilatedConvFn(torch.autograd.Function):
@@ -292,7 +341,7 @@ class _DilatedConvFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, weight, bias, dilation, causal):
+    def forward(ctx, x, weight, bias, dilation, causal, grad_enabled):
         lib = _lib.load()
         _require_device(x, "input")
         _require_device(weight, "weight")
@@ -315,7 +364,7 @@ class _DilatedConvFn(torch.autograd.Function):
         load_series(xin.t, x.detach(), layout)
         y = Lease(B, Co, layout, dev)
         _lib.check(lib.wn_conv_forward(ctypes.byref(shape), _p(packed), _p(xin), _p(y), _stream()), "wn_conv_forward")
-        if any(ctx.needs_input_grad):
+        if grad_enabled and any(ctx.needs_input_grad):
             ctx.saved = (xin, packed, shape)
         ctx.layout, ctx.dims, ctx.has_bias = layout, (B, Ci, Co, k), bias is not None
         return _own(y.view())
@@ -344,11 +393,11 @@ class _DilatedConvFn(torch.autograd.Function):
         _lib.check(lib.wn_conv_backward_weights(ctypes.byref(shape), _p(xin), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes,
                                                 _stream()), "wn_conv_backward_weights")
         ctx.saved = None
-        return dx0, dw, db, None, None
+        return dx0, dw, db, None, None, None
 
 
 def dilated_conv(x, weight, bias, dilation=1, causal=True):
-    return _DilatedConvFn.apply(x, weight, bias, int(dilation), bool(causal))
+    return _DilatedConvFn.apply(x, weight, bias, int(dilation), bool(causal), torch.is_grad_enabled())
 
 
 class _SequenceNLLFn(torch.autograd.Function):
@@ -366,7 +415,14 @@ class _SequenceNLLFn(torch.autograd.Function):
         tg = target.contiguous()
         lse = torch.empty(B, L, dtype=torch.float32, device=x.device)
         partial = torch.empty(lib.wn_nll_partials(B, L), dtype=torch.float32, device=x.device)
-        _lib.check(lib.wn_nll_forward(_p(x), _p(tg), _p(lse), _p(partial), B, C, L, _stream()), "wn_nll_forward")
+        bad = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _lib.check(lib.wn_nll_forward(_p(x), _p(tg), _p(lse), _p(partial), _p(bad), B, C, L, _stream()), "wn_nll_forward")
+        # the kernel never indexes the logits with an out-of-range label (it counts it and poisons the loss with NaN);
+        # turning the count into an exception costs one device->host read per call (WN_NLL_CHECK=0 skips it)
+        if os.environ.get("WN_NLL_CHECK", "1") != "0":
+            nbad = int(bad.item())
+            if nbad:
+                raise RuntimeError("wavenet_speech_amd: sequence_nll got %d target(s) outside [0, %d)" % (nbad, C))
         ctx.save_for_backward(x, tg, lse)
         return partial.sum() / B
 

@@ -88,12 +88,61 @@ def fold_bottlenecks(blocks, bottlenecks):
     return list(wf.unbind(0)), list(bf.unbind(0))
 
 
-def run_stack(out, blocks, bottlenecks):
+class StackState(object):
+    """Per-model state of the fused stack path: the arithmetic mode and, for inference, the folded bottlenecks and
+    packed weights kept across forwards while no parameter changes (functional.PackCache)."""
+
+    def __init__(self):
+        self.precision = "f32"
+        self.cache = HF.PackCache()
+        self.folded = None
+
+
+PRECISIONS = ("f32", "f16x3", "f16", "bf16")
+
+
+def set_precision(module, precision):
+    """Select the arithmetic of the residual stacks of `module` (a WaveNet / RawCTCNet / WaveNetClassifier or anything
+    containing them): "f32" exact fp32 MFMA (default); "f16x3" fp16 MFMA with every operand split into a high and a low
+    half (3 products, fp32 accumulate: fp32-equivalent results at 3/16 of the fp32 MFMA cost); "f16" / "bf16" plain
+    half-precision storage and MFMA with fp32 accumulation (BASELINE configs[4] / configs[1])."""
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
+    n = 0
+    for m in module.modules():
+        st = getattr(m, "stack_state", None)
+        if isinstance(st, StackState):
+            st.precision = precision
+            st.cache = HF.PackCache()
+            n += 1
+    if n == 0:
+        raise ValueError("set_precision: no residual stack in %s" % type(module).__name__)
+    return module
+
+
+def run_stack(out, blocks, bottlenecks, state=None):
     """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path"""
     specs, flat = [], []
     out_dim = bottlenecks[0].out_channels
-    wfs, bfs = fold_bottlenecks(list(blocks), list(bottlenecks))
+    blocks, bottlenecks = list(blocks), list(bottlenecks)
+    precision = state.precision if state is not None else "f32"
+    cache = None
+    inference = state is not None and not torch.is_grad_enabled()
+    if inference:
+        # nothing is differentiated: the folds and the packed weights depend only on the parameters, keep them
+        # until one of those is updated in place (its _version changes) or replaced
+        cache = state.cache
+        params = [p for m in blocks + bottlenecks for p in m.parameters()]
+        old_key = cache.key
+        cache.validate(params, (precision,))
+        if state.folded is None or cache.key != old_key:
+            state.folded = fold_bottlenecks(blocks, bottlenecks)
+        wfs, bfs = state.folded
+    else:
+        wfs, bfs = fold_bottlenecks(blocks, bottlenecks)
+        if state is not None:
+            state.folded = None
     for blk, w, b in zip(blocks, wfs, bfs):
         specs.append(blk.spec(out_dim))
         flat.extend(blk.hip_params(w, b))
-    return HF.residual_stack(out, specs, flat)
+    return HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache)

@@ -5,7 +5,7 @@ same non-causal residual stack); consumes WaveNet's output distribution in the j
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, run_stack
+from .block import ResidualBlock, StackState, run_stack
 from .pointwise import run_sequential
 
 
@@ -18,6 +18,7 @@ class WaveNetClassifier(nn.Module):
         self.pool_kernel_size, self.pool_padding = pool_kernel_size, 0
         self.input_kernel_size, self.input_dilation = input_kernel_size, input_dilation
         self.softmax = softmax
+        self.stack_state = StackState()
 
         self.mean_pool = nn.AvgPool1d(kernel_size=pool_kernel_size, padding=self.pool_padding)
         self.input_block = ResidualBlock(in_dim, layers[0][0], input_kernel_size, input_dilation, causal=False)
@@ -40,7 +41,7 @@ class WaveNetClassifier(nn.Module):
     def forward(self, seq):
         out = self.mean_pool(seq)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
-                              [self.input_skip_bottleneck] + list(self.bottlenecks))
+                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
         logit_seq = run_sequential(self.output_block, skips_sum)
         if not self.softmax:
             return logit_seq

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, run_stack
+from .block import ResidualBlock, StackState, run_stack
 from .pointwise import run_sequential
 
 
@@ -18,6 +18,7 @@ class RawCTCNet(nn.Module):
         self.layers, self.num_layers, self.out_dim = layers, len(layers), out_dim
         self.input_kernel_size, self.input_dilation = input_kernel_size, input_dilation
         self.positions, self.softmax, self.causal = positions, softmax, causal
+        self.stack_state = StackState()
 
         # padding = k-1 on both sides: the sequence grows to L + k - 1 (reference modules/raw_ctcnet.py:57-61)
         self.feature_layer = nn.Sequential(
@@ -60,7 +61,7 @@ class RawCTCNet(nn.Module):
             steps = torch.arange(0., out.size(2), device=seq.device).view(1, 1, -1)
             out = out + run_sequential(self.positions_conv1x1, steps)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
-                              [self.input_skip_bottleneck] + list(self.bottlenecks))
+                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
         logit_seq = run_sequential(self.output_block, skips_sum)
         if not self.softmax:
             return logit_seq

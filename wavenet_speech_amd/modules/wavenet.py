@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, run_stack
+from .block import ResidualBlock, StackState, run_stack
 from .conv_ops import CausalConv1d
 from .pointwise import run_sequential
 
@@ -26,6 +26,7 @@ class WaveNet(nn.Module):
         self.in_dim, self.entry_kwidth = in_dim, entry_kwidth
         self.layers, self.num_layers = layers, len(layers)
         self.out_dim, self.softmax = out_dim, softmax
+        self.stack_state = StackState()   # arithmetic mode + inference weight cache (not a parameter/buffer)
 
         self.entry_conv1d = CausalConv1d(in_dim, layers[0][0], entry_kwidth, dilation=1)
         self.convolutions = nn.ModuleList([ResidualBlock(ci, co, k, d) for (ci, co, k, d) in layers])
@@ -44,7 +45,7 @@ class WaveNet(nn.Module):
 
     def forward(self, signal):
         out = self.entry_conv1d(signal)
-        skips_sum = run_stack(out, self.convolutions, self.bottlenecks)
+        skips_sum = run_stack(out, self.convolutions, self.bottlenecks, self.stack_state)
         output_seq = run_sequential(self.output_stack, skips_sum)
         if not self.softmax:
             return output_seq

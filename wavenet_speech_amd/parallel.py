@@ -18,6 +18,26 @@ def shard_bounds(global_batch, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+class _Done(object):
+    def wait(self):
+        return True
+
+
+class _PendingAverage(object):
+    """handle of an asynchronous flat-gradient all-reduce: wait() finishes the collective, then divides by world"""
+
+    def __init__(self, work, flat, scale):
+        self.work, self.flat, self.scale = work, flat, scale
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.scale != 1:
+                self.flat.div_(self.scale)
+        return True
+
+
 class FlatGradAllReduce(object):
     """All parameter gradients of a replica in ONE flat buffer, all-reduced with ONE collective.
 
@@ -68,15 +88,18 @@ class FlatGradAllReduce(object):
             p.grad = v
 
     def reduce(self, async_op=False):
+        """gather + all-reduce (+ 1/world).  async_op=True returns a handle whose wait() completes the collective AND
+        applies the 1/world average (call it before optimizer.step()); otherwise returns None when done."""
         self.gather()
         if not (dist.is_available() and dist.is_initialized()):
-            return None
+            return _Done() if async_op else None
         w = self.world()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        scale = w if (self.average and w > 1) else 1
         if async_op:
-            return work
-        if self.average and w > 1:
-            self.flat.div_(w)
+            return _PendingAverage(work, self.flat, scale)
+        if scale != 1:
+            self.flat.div_(scale)
         return None
 
     def payload_bytes(self):

@@ -51,7 +51,7 @@ class _Pool(object):
             lst = self._free.get(key)
             if lst:
                 t = lst.pop()
-                self.free_bytes -= t.numel() * 4
+                self.free_bytes -= t.numel() * t.element_size()
                 self._free.move_to_end(key)
                 return t
         return None
@@ -70,13 +70,13 @@ class _Pool(object):
         with self._lock:
             self._free.setdefault(key, []).append(tensor)
             self._free.move_to_end(key)
-            self.free_bytes += tensor.numel() * 4
+            self.free_bytes += tensor.numel() * tensor.element_size()
             while self.free_bytes > cap and self._free:
                 old_key = next(iter(self._free))
                 if old_key == key and len(self._free) == 1:
                     break
                 for t in self._free.pop(old_key):
-                    self.free_bytes -= t.numel() * 4
+                    self.free_bytes -= t.numel() * t.element_size()
 
     def clear(self):
         with self._lock:
@@ -91,13 +91,27 @@ class Lease(object):
     """A pooled series buffer.  `.t` is the [B][Cp][ld] tensor, `.ptr` its device address."""
     __slots__ = ("t", "ptr", "_key", "channels", "layout", "__weakref__")
 
-    def __init__(self, batch, channels, layout, device):
-        cp = round_up(channels, 8)
-        # the zero-padding invariant is tied to the exact valid window, so C, L and halo are part of the key
-        self._key = (str(device), batch, channels, layout.length, layout.halo, layout.ld)
+    def __init__(self, batch, channels, layout, device, dtype=torch.float32, rows=None, pitch=None):
+        """rows / pitch override the [round_up(C, 8)][ld] plane geometry (the half-precision layouts of
+        functional_half use [planes * C/8][ld * 8] halves)."""
+        cp = round_up(channels, 8) if rows is None else rows
+        ld = layout.ld if pitch is None else pitch
+        # The zero-padding invariant is tied to the exact valid window, so C, L and halo are part of the key -- and so is
+        # the STREAM the lease is taken on: a buffer returns to the pool when its last Python reference dies, which can be
+        # while its last kernel is still queued.  Handing it to a later lease on the same stream is safe (stream order);
+        # handing it to another stream would not be, so buffers never migrate between streams.
+        dev = torch.device(device)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        self._key = (str(dev), stream, batch, channels, layout.length, layout.halo, layout.ld, dtype, cp, ld)
         t = POOL.take(self._key)
         if t is None:
-            t = torch.zeros(batch, cp, layout.ld, dtype=torch.float32, device=device)
+            try:
+                t = torch.zeros(batch, cp, ld, dtype=dtype, device=dev)
+            except torch.OutOfMemoryError:
+                # the pool's idle buffers are invisible to torch's caching allocator: give them back and retry once
+                POOL.clear()
+                torch.cuda.empty_cache()
+                t = torch.zeros(batch, cp, ld, dtype=dtype, device=dev)
         self.t = t
         self.ptr = t.data_ptr()
         self.channels = channels
