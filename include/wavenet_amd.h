@@ -183,6 +183,57 @@ int wn_nll_forward(const float* logits, const long long* target, float* lse, flo
 int wn_nll_backward(const float* logits, const long long* target, const float* lse, const float* gscale, float* dlogits,
                     int batch, int classes, int length, wn_stream_t stream);
 
+/* ======================================================================================================================
+ * Half-precision-MFMA modes of the same path (opt-in; the entry points above stay exact fp32).
+ *
+ *   WN_F16X3  every operand is split into two fp16 planes (hi, lo); each product is hi*hi + hi*lo + lo*hi on
+ *             v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-equivalent results at 3/16 of the fp32 MFMA cost.
+ *   WN_F16 / WN_BF16   one plane of fp16 / bf16 storage, one MFMA per product, fp32 accumulation
+ *             (the dtypes BASELINE.json configs[4] / configs[1] name).
+ *
+ * "Half series" layout of every activation:  T buf[B][P][G][ld][8],  P = planes (2 for F16X3), G = round_up(C,32)/8;
+ *   sample (b, c, t) of plane p at ((((b*P + p)*G + c/8)*ld + halo + t)*8 + c%8.  Eight channels of one time step are one
+ *   16-byte unit = one MFMA operand fragment; a dilated tap is the same unit stream at another start.  Halos, the tail up to
+ *   ld (= 2*halo + round_up(L, 256)) and the pad channels MUST be zero on input and are kept zero.
+ * Power-of-two scales (exact): the residual stream (x, r_out) is stored as value * wn_hseries_residual_scale() (= 1/16, so
+ *   fp16 holds |r| up to 1e6); ta, sg, z as is; every gradient series as value * s, where s is one DEVICE scalar per
+ *   backward call chosen by the caller (pass 1/s as dyn_inv_scale where results leave the half domain).
+ * fp16 stores that overflow (|v| > 65504) set *overflow_flag (a DEVICE unsigned the caller zeroed; may be NULL) to 1.
+ * Everything else (ownership, streams, status codes, dr == NULL for the last block) is as for the fp32 entry points, whose
+ * reference counterparts (modules/block.py:54-82, modules/wavenet.py:98-100) these replace in the same way. */
+typedef enum wn_precision { WN_F32 = 0, WN_F16X3 = 1, WN_F16 = 2, WN_BF16 = 3 } wn_precision;
+
+int wn_hseries_layout(int length, int max_abs_offset, int* ld, int* halo);
+size_t wn_hseries_bytes(int precision, int batch, int channels, int ld);
+float wn_hseries_residual_scale(void);
+/* dense fp32 [B][C][L] -> half series, multiplied by scale * (dyn_scale ? *dyn_scale : 1).  Only the valid window is written. */
+int wn_hseries_load(int precision, const float* dense, void* series, int batch, int channels, int length, int ld, int halo,
+                    float scale, const float* dyn_scale, unsigned* overflow_flag, wn_stream_t stream);
+
+size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision);
+int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream);
+/* x, r_out (nullable), ta, sg (nullable together), z: half series.  skip_dense (nullable): dense fp32 [B][Ms][L] that
+ * receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference. */
+int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
+                      float* skip_dense, int skip_accumulate, void* ta, void* sg, void* z, unsigned* overflow_flag,
+                      wn_stream_t stream);
+size_t wn_hskipsum_packed_bytes(const wn_skipsum_shape* s, int precision);
+int wn_hskipsum_pack(const wn_skipsum_shape* s, int precision, const float* const* w_skip, const float* bias_total,
+                     void* packed, wn_stream_t stream);
+/* z[l]: half series of every block; skip_dense: dense fp32 [B][Ms][L] */
+int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* packed, const void* const* z,
+                        float* skip_dense, int accumulate, wn_stream_t stream);
+/* dr (nullable), dskip, ta, sg, da, dg: half series (gradients carry the scale s).  The input gradient goes either to the
+ * half series dx (scaled by s, the next block's dr) or to dense fp32 dx_dense [B][Ci][L] multiplied by *dyn_inv_scale. */
+int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                            const void* ta, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                            const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream);
+size_t wn_hblock_wgrad_workspace_bytes(const wn_block_shape* s, int precision);
+/* gradients in PyTorch layouts, fp32, multiplied by *dyn_inv_scale (and by the residual-stream scale where x is an operand) */
+int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const void* x, const void* z, const void* da,
+                               const void* dg, const void* dr, const void* dskip, const wn_block_params* grads,
+                               const float* dyn_inv_scale, void* workspace, size_t workspace_bytes, wn_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of every kernel on its launch stream ----
  * Kernel classes: index into wn_prof_kernel_name().  wn_prof_collect() synchronises the recorded
  * events and adds them to the per-class totals; wn_prof_get() reads them. */

@@ -1,0 +1,138 @@
+"""GPU parity of the half-precision-MFMA modes of the residual stack (wavenet_speech_amd.set_precision).
+
+f16x3 (three-product fp16 split, fp32 accumulate) is held to the SAME 1e-4 bar as the exact-fp32 path, forward and every
+gradient, on the golden fixtures and against the oracle.  Plain f16 / bf16 (BASELINE configs[4] / configs[1]) are checked
+against the oracle with the error their storage format implies; the measured errors are printed."""
+import pytest
+import torch
+
+import wavenet_speech_amd as W
+from oracle import wavenet_oracle as O
+from tests import goldenio
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+LOOSE = {"f16": 2e-2, "bf16": 1.2e-1}     # max-norm relative error bounds of the plain modes on the small nets below
+
+
+def _cond_wavenet(c, layers, in_dim=None, seed=0):
+    from wavenet_speech_amd.modules.wavenet import WaveNet
+    torch.manual_seed(seed)
+    net = WaveNet(in_dim or c, 2, layers, c, softmax=False)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn(p.shape))
+        for blk in net.convolutions:
+            blk.residual_proj.weight.copy_(torch.eye(blk.out_channels, blk.in_channels)
+                                           + 0.02 * torch.randn(blk.out_channels, blk.in_channels))
+            blk.conv1x1_residual.weight.mul_(0.3)
+    return net
+
+
+def _run(net, x, cot, layers, precision, tol, replay_slopes=True):
+    sd = {k: v.clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    W.set_precision(net, precision)
+    slopes, remove = O.capture_leaky_slopes(net)
+    xg = x.to(DEV).requires_grad_(True)
+    y1 = net(xg)
+    remove()
+    (y1 * cot.to(DEV)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    y0 = O.wavenet(xr, sd, layers, False, slopes=slopes if replay_slopes else None)
+    (y0 * cot).sum().backward()
+    errs = {"forward": O.rel_err(y1.detach().cpu(), y0), "dx": O.rel_err(xg.grad.cpu(), xr.grad)}
+    for k, p in net.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None, k
+            continue
+        errs[k] = O.rel_err(p.grad.cpu(), sd[k].grad)
+    worst = max(errs, key=errs.get)
+    print("%s: forward %.2e, dx %.2e, worst gradient %s %.2e" % (precision, errs["forward"], errs["dx"], worst, errs[worst]))
+    assert errs[worst] < tol, (worst, errs[worst])
+    return errs
+
+
+@pytest.mark.parametrize("shape", [(32, 4, 300, 2), (48, 3, 1000, 1), (20, 2, 77, 3), (64, 5, 515, 2)])
+def test_f16x3_small_wavenets_vs_oracle(shape):
+    c, nblk, L, B = shape
+    layers = [(c, c, 2, 2 ** i) for i in range(nblk)]
+    net = _cond_wavenet(c, layers, seed=c)
+    g = torch.Generator().manual_seed(L)
+    x, cot = torch.randn(B, c, L, generator=g), torch.randn(B, c, L, generator=g)
+    _run(net, x, cot, layers, "f16x3", TOL)
+
+
+def test_f16x3_mixed_widths_k3_and_dilation_beyond_length():
+    layers = [(24, 40, 3, 1), (40, 40, 2, 7), (40, 72, 2, 300), (72, 72, 3, 2)]
+    from wavenet_speech_amd.modules.wavenet import WaveNet
+    torch.manual_seed(9)
+    net = WaveNet(10, 2, layers, 36, softmax=False)
+    g = torch.Generator().manual_seed(10)
+    x, cot = torch.randn(2, 10, 260, generator=g), torch.randn(2, 36, 260, generator=g)
+    _run(net, x, cot, layers, "f16x3", TOL)
+
+
+@pytest.mark.parametrize("name", goldenio.names("wavenet_") + goldenio.names("rawctc_") + goldenio.names("classifier_"))
+def test_f16x3_golden_models(name):
+    """the reference's own outputs and autograd gradients (tests/golden) through the f16x3 stack, same tolerance as fp32"""
+    from tests.test_gpu_parity import _mods, _run_golden
+    g = goldenio.load(name)
+    m = g.meta
+    M = _mods()
+    if m["kind"] == "wavenet":
+        net = M.WaveNet(m["in_dim"], m["entry_kwidth"], m["layers"], m["out_dim"], softmax=m["softmax"])
+    elif m["kind"] == "rawctc":
+        net = M.RawCTCNet(m["num_features"], m["feature_kwidth"], m["num_labels"], m["layers"], m["out_dim"],
+                          input_kernel_size=m["input_kernel_size"], input_dilation=m["input_dilation"],
+                          positions=m["positions"], softmax=m["softmax"], causal=m["causal"])
+    else:
+        net = M.WaveNetClassifier(m["in_dim"], m["num_labels"], m["layers"], m["out_dim"],
+                                  pool_kernel_size=m["pool_kernel_size"], input_kernel_size=m["input_kernel_size"],
+                                  input_dilation=m["input_dilation"], softmax=m["softmax"])
+    W.set_precision(net, "f16x3")
+    _run_golden(g, net)
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_plain_half_modes_vs_oracle(precision):
+    c, L, B = 64, 600, 2
+    layers = [(c, c, 2, 2 ** i) for i in range(6)]
+    net = _cond_wavenet(c, layers, seed=5)
+    g = torch.Generator().manual_seed(6)
+    x, cot = torch.randn(B, c, L, generator=g), torch.randn(B, c, L, generator=g)
+    errs = _run(net, x, cot, layers, precision, LOOSE[precision])
+    print(precision, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]})
+
+
+def test_half_inference_matches_training_forward_and_is_deterministic():
+    c = 64
+    layers = [(c, c, 2, 2 ** i) for i in range(5)]
+    net = _cond_wavenet(c, layers, seed=11).to(DEV)
+    W.set_precision(net, "f16x3")
+    x = torch.randn(2, c, 400, device=DEV)
+    y_train = net(x).detach()
+    with torch.no_grad():
+        y_eval = net(x)
+        y_eval2 = net(x)
+    assert O.rel_err(y_eval.cpu(), y_train.cpu()) < 1e-5
+    assert torch.equal(y_eval, y_eval2)
+    W.set_precision(net, "f32")
+    with torch.no_grad():
+        y32 = net(x)
+    assert O.rel_err(y_eval.cpu(), y32.cpu()) < 1e-5
+
+
+def test_fp16_overflow_is_loud():
+    """fp16 holds the residual stream up to 16 * 65504: beyond that the call must fail, not return inf/garbage"""
+    c = 32
+    layers = [(c, c, 2, 1), (c, c, 2, 2)]
+    net = _cond_wavenet(c, layers, seed=13).to(DEV)
+    W.set_precision(net, "f16x3")
+    x = torch.randn(1, c, 100, device=DEV) * 3e6
+    with pytest.raises(RuntimeError, match="overflow"):
+        net(x)
+    W.set_precision(net, "bf16")
+    assert bool(torch.isfinite(net(x)).all())

@@ -6,7 +6,7 @@ fails, a RuntimeError is raised.  Nothing here touches torch.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_amd.so")
@@ -74,6 +74,23 @@ SIGNATURES = {
     "wn_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvShape)]),
     "wn_conv_backward_weights": (c_int, [POINTER(ConvShape), c_float_p, c_float_p, c_float_p, c_float_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "wn_hseries_layout": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "wn_hseries_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wn_hseries_residual_scale": (c_float, []),
+    "wn_hseries_load": (c_int, [c_int, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float_p, c_void_p,
+                                c_void_p]),
+    "wn_hblock_packed_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
+    "wn_hblock_pack": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p]),
+    "wn_hblock_forward": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wn_hskipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape), c_int]),
+    "wn_hskipsum_pack": (c_int, [POINTER(SkipSumShape), c_int, POINTER(c_void_p), c_float_p, c_void_p, c_void_p]),
+    "wn_hskipsum_forward": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
+    "wn_hblock_backward_data": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_float_p, c_float_p, c_void_p, c_void_p]),
+    "wn_hblock_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
+    "wn_hblock_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, POINTER(BlockParams), c_float_p, c_void_p, c_size_t, c_void_p]),
     "wn_nll_partials": (c_size_t, [c_int, c_int]),
     "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
@@ -125,6 +142,15 @@ def tap_offsets(k, d, causal):
 def series_layout(length, max_abs_offset):
     ld, halo = c_int(), c_int()
     check(load().wn_series_layout(length, max_abs_offset, ctypes.byref(ld), ctypes.byref(halo)), "wn_series_layout")
+    return ld.value, halo.value
+
+
+PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3}   # wn_precision
+
+
+def hseries_layout(length, max_abs_offset):
+    ld, halo = c_int(), c_int()
+    check(load().wn_hseries_layout(length, max_abs_offset, ctypes.byref(ld), ctypes.byref(halo)), "wn_hseries_layout")
     return ld.value, halo.value
 
 

@@ -35,6 +35,11 @@ int hip_fail(hipError_t e, const char* what) {
         if (e__ != hipSuccess) return hip_fail(e__, what);  \
     } while (0)
 
+}  // namespace
+namespace wn {
+int hip_fail_shared(hipError_t e, const char* what) { return hip_fail(e, what); }   // for the other host translation units
+}
+namespace {
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int tiles32(int c) { return cdiv(c, 32); }
@@ -45,14 +50,17 @@ inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 // ------------------------------------------------------------------------------------------
 // profiling (HIP events on the launch stream)
 // ------------------------------------------------------------------------------------------
-enum KernelClass {
+enum KernelClass {   // the half-precision classes (KC_HLOAD...) are used by wn_half_api.hip, which repeats this order
     KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE,
-    KC_CONV_FWD, KC_CONV_BWD_DATA, KC_SKIP_GEMM, KC_COUNT
+    KC_CONV_FWD, KC_CONV_BWD_DATA, KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED,
+    KC_COUNT
 };
 const char* const kKernelNames[KC_COUNT] = {
     "pack_kernel", "series_gemm_kernel<gate>", "series_gemm_kernel<res>", "series_gemm_kernel<dz,dgate>",
     "series_gemm_kernel<dx>", "wgrad_kernel", "wgrad_reduce_kernel", "series_gemm_kernel<conv_fwd>",
-    "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skips_sum>"};
+    "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skips_sum>", "hload_kernel", "hgemm_kernel<gate>",
+    "hgemm_kernel<res>", "hgemm_kernel<dz,dgate>", "hgemm_kernel<dx>", "hgemm_kernel<skips_sum>", "hwgrad_kernel",
+    "embed_kernel"};
 
 struct ProfRec { int kc; hipEvent_t e0, e1; double flops; };
 struct Prof {
@@ -93,6 +101,17 @@ struct ProfScope {
     }
 };
 
+}  // namespace
+namespace wn {
+struct ProfScopeShared {   // the same scope for wn_half_api.hip / wn_embed.hip
+    void* impl;
+    ProfScopeShared(int kc, double flops, hipStream_t st);
+    ~ProfScopeShared();
+};
+ProfScopeShared::ProfScopeShared(int kc, double flops, hipStream_t st) : impl(new ProfScope(kc, flops, st)) {}
+ProfScopeShared::~ProfScopeShared() { delete static_cast<ProfScope*>(impl); }
+}  // namespace wn
+namespace {
 // ------------------------------------------------------------------------------------------
 // geometry
 // ------------------------------------------------------------------------------------------
@@ -605,6 +624,7 @@ int run_wgrad(const std::vector<PairSpec>& ps, int maxdim, int B, int L, int ld,
         d.w = ps[i].w; d.M = ps[i].a_rows; d.N = ps[i].b_rows; d.sm = ps[i].sm; d.sn = ps[i].sn;
         d.slab_off = wp.slab_off[i]; d.Np = wp.Np[i];
         d.b0 = ps[i].rowsum ? ps[i].b0 : nullptr; d.b1 = ps[i].rowsum ? ps[i].b1 : nullptr; d.rs_off = wp.rs_off[i];
+        d.post = 1.0f;
         flops += 2.0 * ps[i].a_rows * (double)ps[i].b_rows * (double)B * L;
     }
     a.npair = wp.npair; a.ntile_total = wp.ntile_total; a.nsplit = wp.nsplit; a.xcd_map = wp.xcd_map() ? 1 : 0;

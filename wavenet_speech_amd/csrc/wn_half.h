@@ -1,0 +1,138 @@
+// Internal declarations of the half-precision-MFMA path (wn_half*.hip).  Not part of the C ABI.
+//
+// "Half series" layout (every activation of the half path): planes x channel-groups x time x 8 channels
+//     T buf[B][P][G][ld][8],   T = _Float16 or __bf16,  G = round_up(C, 32) / 8,  P = planes
+//     sample (b, c, t) -> plane p value at ((((b*P + p)*G + c/8)*ld + halo + t)*8 + c%8
+//   P = 2 for "f16x3": plane 0 = hi = fp16(x*s), plane 1 = lo = fp16(x*s - hi)  (x*s ~ hi + lo to 22 bits);
+//   P = 1 for plain f16 / bf16.  `s` is a power-of-two scale that belongs to the tensor (1 for ta/sg/z, kResidualScale
+//   for the residual stream, a per-call dynamic scale for every gradient tensor).
+//   Eight consecutive channels of one time step are one 16-byte unit: exactly the B-operand fragment of
+//   v_mfma_f32_32x32x16_{f16,bf16} (lane (n, h) holds k = 8h..8h+7 of column n), so a tile of the series is staged into
+//   LDS by global_load_lds_dwordx4 with no conversion, and a dilated tap x[t+off] is the same load at another start
+//   unit -- always 16-byte aligned.  Halos, the tail up to ld and the pad channels are zero and stay zero.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wn_kernels.h"
+
+namespace wn {
+
+enum { HP_F16X3 = 1, HP_F16 = 2, HP_BF16 = 3 };   // = wn_precision values of include/wavenet_amd.h
+constexpr int kHCol = 256;          // time steps per workgroup tile of hgemm_kernel
+constexpr int kHMaxSlab = 8;        // WN_MAX_CHANNELS * 2 / 256
+constexpr float kResidualScale = 0.0625f;   // the residual stream is stored as r/16: fp16 then holds |r| up to 1.0e6
+constexpr float kWeightScale = 256.0f;      // weights are packed as 256*w: kaiming-sized weights (~0.05) sit in fp16's normal range
+
+inline __host__ __device__ int hp_planes(int prec) { return prec == HP_F16X3 ? 2 : 1; }
+
+struct HSeg {               // one K-segment: `nks` k-steps (16 channels each) of one half series read at column offset `off`
+    const char* base;
+    long long ustride;      // bytes per utterance  (P * G * ld * 16)
+    long long pstride;      // bytes per plane      (G * ld * 16)
+    int off;
+    int nks;
+};
+
+struct HSlab {
+    long long woff;         // byte offset of this slab's packed weights
+    int nseg;               // leading segments this slab contracts over
+    int row0;               // first destination row / channel
+    int boff;               // float offset of this slab's bias (ROWS floats)
+    int dst;
+};
+
+struct HDst {               // a half-series destination (or source, for the dgate epilogue)
+    char* base;
+    long long ustride, pstride;
+    int cp;                 // padded channels (8 * G); rows >= cp are not stored
+    int _pad;
+};
+
+enum { HEPI_STORE = 0, HEPI_GATE = 1, HEPI_DGATE = 2, HEPI_F32 = 3 };
+
+struct HGemmArgs {
+    const char* wpacked;
+    const float* bias;      // packed fp32, already multiplied by the output scale; may be nullptr
+    HSeg seg[kMaxSeg];
+    HSlab slab[kHMaxSlab];
+    HDst dst[2];            // HEPI_STORE: dst[slab.dst]
+    HDst ta, sg, z;         // HEPI_GATE out (ta.base may be nullptr: inference) / HEPI_DGATE in
+    HDst da, dg;            // HEPI_DGATE out
+    float* out32;           // HEPI_F32: dense [B][out32_rows][L] fp32
+    const float* dyn_inv;   // HEPI_F32: optional device scalar multiplied into the result (1 / dynamic gradient scale)
+    unsigned* flag;         // set to 1 when an fp16 store overflowed (|v| > 65504)
+    float oscale;           // accumulators are multiplied by this exact power of two
+    int out32_rows, out32_accum;
+    int gate_rows;          // valid channels of the gate epilogues
+    int nslab, B, L, ld, halo;
+    int tiles_per_row, ncol;
+};
+
+// ---- weight packing ------------------------------------------------------------------------------------------
+struct HPackSrc {
+    const float* ptr;       // nullptr => zeros
+    int rows, cols;
+    int stride_r, stride_c;
+    float scale;            // multiplied into the weight (weight scale / input-tensor scale), exact power of two
+    int _pad;
+};
+struct HPackSet {
+    HPackSrc seg[kMaxSeg];
+    const float* bias0;
+    const float* bias1;
+    int bias_rows;
+    float bias_scale;
+};
+struct HPackArgs {
+    HPackSet set[2];
+    PackTile tile[kHMaxSlab * 8];   // [slab * (ROWS/32) + row tile]: source set and its first row (row0 < 0: zero tile)
+    int seg_nks[kMaxSeg];
+    long long slab_woff[kHMaxSlab]; // bytes
+    int slab_nseg[kHMaxSlab];
+    int slab_boff[kHMaxSlab];
+    int nslab, rows;                // rows per slab (64 * MT)
+    int planes, bf16;
+    char* wpacked;
+    float* bias;
+    long long total_units;          // 16-byte units per plane over all slabs
+};
+
+// ---- dense fp32 <-> half series --------------------------------------------------------------------------------
+struct HLoadArgs {
+    const float* src;       // dense [B][C][L]
+    char* dst;              // half series
+    const float* dyn_scale; // optional device scalar multiplied into the values
+    unsigned* flag;
+    float scale;
+    int B, C, L, G, ld, halo, planes, bf16;
+};
+
+// ---- weight gradients ------------------------------------------------------------------------------------------
+struct HWgradPair {
+    const char* A; const char* Bm;      // half series
+    long long a_ustride, a_pstride, b_ustride, b_pstride;
+    int a_groups, b_groups;             // channel groups (padded channels / 8) the operands really have
+    int off;                            // column offset on the B side
+    int mt, nt;                         // 256-row / 256-column workgroup tiles
+    int tile0;
+    long long slab_off;                 // float offset of this pair's [Mp x Np] block inside a split's slab
+    int Mp, Np;
+    int rowsum, rs_off;
+};
+struct HWgradArgs {
+    HWgradPair pair[kMaxPair];
+    int npair, ntile_total, nsplit, xcd_map;
+    int B, L, ld, halo;
+    int steps_per_row;                  // ceil(L / 16) k-steps per utterance
+    int nstep;                          // B * steps_per_row
+    float* slab; float* rowsum;
+    long long slab_floats; int rs_floats;
+};
+
+hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);
+hipError_t launch_hpack(const HPackArgs& a, hipStream_t st);
+hipError_t launch_hload(const HLoadArgs& a, hipStream_t st);
+hipError_t launch_hwgrad(int prec, const HWgradArgs& a, hipStream_t st);
+
+}  // namespace wn

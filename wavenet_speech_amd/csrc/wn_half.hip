@@ -1,0 +1,505 @@
+// Half-precision-MFMA series GEMM for gfx950 (MI355X): the LDS-tiled kernel behind the "f16x3", "f16" and "bf16" modes
+// of the residual-block stack.
+//
+//   out[M x (B*L)] = Wpacked[M x K] * Bop[K x (B*L)]       on v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate
+//
+// f16x3: every operand is a pair of fp16 planes (hi, lo) and every algorithmic product is three MFMAs
+// (hi*hi + hi*lo + lo*hi; the lo*lo term is below fp32 rounding), i.e. fp32-equivalent results at 3/16 of the cost of
+// v_mfma_f32_32x32x2_f32.  f16 / bf16: one plane, one MFMA.
+//
+// Why a different kernel from series_gemm_kernel: at 16x the MFMA rate a wave can no longer be fed from L2 directly
+// (tools/f16x3_probe.hip: 43 B/clk/CU of fragments, 1.4x instead of ~5x), so operands are shared through LDS:
+//  * workgroup = 4 waves (2 x 2) owning (64*MT) rows x 256 time steps; each wave keeps MT x 4 accumulator tiles of
+//    32x32 (256 registers at MT=4, one wave per SIMD).
+//  * one LDS stage = ONE MFMA k-step (16 channels): the weight tile [plane][k-group 2][row][8] and the activation tile
+//    [plane][k-group 2][time 256][8], both as 16-byte units in exactly the order the fragments are read, so
+//    ds_read_b128 is conflict-free (a 16-lane group reads 16 consecutive units) and staging is pure LDS-DMA
+//    (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, no conversion: the half-series layout of
+//    wn_half.h IS the fragment layout; weights are pre-packed in LDS-image order).
+//  * a ring of D stages (128 KiB), D-1 k-steps of prefetch in flight, ONE raw s_barrier per k-step and a counted
+//    s_waitcnt vmcnt(N) -- never 0 inside the loop.
+//  * the same XCD-aware blockIdx mapping as the fp32 kernel: all row slabs of one time tile run on one XCD.
+#include "wn_half.h"
+
+namespace wn {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define WN_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
+                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// value <-> storage helpers
+// ---------------------------------------------------------------------------------------------------------------
+template <bool BF> struct HT;
+template <> struct HT<false> { typedef _Float16 t; typedef h4 v4; typedef h8 v8; };
+template <> struct HT<true> { typedef __bf16 t; typedef b4 v4; typedef b8 v8; };
+
+// The lo plane must be the remainder against EXACTLY the bits stored in the hi plane.  hipcc is free to convert the same
+// fp32 value twice (a packed v_cvt_pk_f16_f32 for the store, a scalar v_cvt_f16_f32 for the subtraction), and on gfx950 the
+// two disagree on exact ties -- measured: 4 of 153 600 elements came out with lo = -half-ulp instead of +half-ulp, an
+// error of one fp16 ulp.  Passing the packed hi through an empty asm makes it opaque: the remainder is then computed from
+// the register that is stored.
+template <typename V>
+__device__ __forceinline__ V pin(V v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// four consecutive channels of one time step -> 8 bytes in plane 0 (and the fp16 remainder in plane 1)
+template <int P, bool BF>
+__device__ __forceinline__ void store4(char* p, long long pstride, const float (&v)[4], unsigned& ovf) {
+    typedef typename HT<BF>::t T;
+    typedef typename HT<BF>::v4 V4;
+    V4 hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hi[q] = (T)v[q];
+    if constexpr (P == 2) hi = pin(hi);
+    *reinterpret_cast<V4*>(p) = hi;
+    if constexpr (!BF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ovf |= (__builtin_fabsf(v[q]) > 65504.0f) ? 1u : 0u;
+    }
+    if constexpr (P == 2) {
+        V4 lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lo[q] = (T)(v[q] - (float)hi[q]);
+        *reinterpret_cast<V4*>(p + pstride) = lo;
+    }
+}
+
+template <int P, bool BF>
+__device__ __forceinline__ void load4(const char* p, long long pstride, float (&v)[4]) {
+    typedef typename HT<BF>::v4 V4;
+    const V4 hi = *reinterpret_cast<const V4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (float)hi[q];
+    if constexpr (P == 2) {
+        const V4 lo = *reinterpret_cast<const V4*>(p + pstride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += (float)lo[q];
+    }
+}
+
+__device__ __forceinline__ float h_sigmoid(float x) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * x);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float h_tanh(float x) {   // same formulation as the fp32 kernel (wn_gemm.hip): |err| <= 2e-7
+    const float ax = __builtin_fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * ax);
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    const float x2 = x * x;
+    const float small = ax * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * -0.0539682540f)));
+    return __builtin_copysignf(ax < 0.125f ? small : big, x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dense fp32 [B][C][L]  ->  half series
+// ---------------------------------------------------------------------------------------------------------------
+template <int P, bool BF>
+__global__ __launch_bounds__(256) void hload_kernel(const HLoadArgs a) {
+    // one thread = one 16-byte unit (8 channels of one time step); lanes run along time, so the eight dword loads of a
+    // wave are 256 contiguous bytes each and the unit stores are 1 KiB contiguous
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per_b = (long long)a.G * a.L;
+    if (idx >= per_b * a.B) return;
+    const int b = (int)(idx / per_b);
+    const long long rem = idx - (long long)b * per_b;
+    const int g = (int)(rem / a.L), t = (int)(rem - (long long)g * a.L);
+    const float s = a.scale * (a.dyn_scale ? a.dyn_scale[0] : 1.0f);
+    typedef typename HT<BF>::t T;
+    typedef typename HT<BF>::v8 V8;
+    V8 hi, lo;
+    float v[8];
+    unsigned ovf = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 8 * g + j;
+        v[j] = c < a.C ? a.src[((long long)b * a.C + c) * a.L + t] * s : 0.0f;
+        hi[j] = (T)v[j];
+        if (!BF) ovf |= (__builtin_fabsf(v[j]) > 65504.0f) ? 1u : 0u;
+    }
+    hi = pin(hi);   // see store4: the remainder must be taken against the stored bits
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lo[j] = (T)(v[j] - (float)hi[j]);
+    const long long pstride = (long long)a.G * a.ld * 16;
+    char* d = a.dst + (long long)b * P * pstride + ((long long)g * a.ld + a.halo + t) * 16;
+    *reinterpret_cast<V8*>(d) = hi;
+    if (P == 2) *reinterpret_cast<V8*>(d + pstride) = lo;
+    if (ovf && a.flag) atomicOr(a.flag, 1u);
+}
+
+hipError_t launch_hload(const HLoadArgs& a, hipStream_t st) {
+    const long long n = (long long)a.B * a.G * a.L;
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (a.planes == 2) hipLaunchKernelGGL((hload_kernel<2, false>), grid, block, 0, st, a);
+    else if (a.bf16) hipLaunchKernelGGL((hload_kernel<1, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((hload_kernel<1, false>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight packing:  PyTorch-layout fp32 parameters -> [slab][k-step][plane][k-group 2][row][8] (the LDS image of a stage)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = one 16-byte unit of plane 0 (+ plane 1)
+    if (idx < a.total_units) {
+        const long long plane_bytes = 2LL * a.rows * 16;               // one k-step of one plane
+        const long long kstep_bytes = plane_bytes * a.planes;
+        int slab = 0;
+        while (slab + 1 < a.nslab && idx * 16 * a.planes >= a.slab_woff[slab + 1]) ++slab;
+        const long long rel = idx - a.slab_woff[slab] / (16 * a.planes);   // unit index inside the slab, plane 0 numbering
+        const int row = (int)(rel % a.rows);
+        const long long kk = rel / a.rows;                             // 2*ks + kg
+        const int kg = (int)(kk & 1);
+        long long ks = kk >> 1;
+        const long long ks_abs = ks;
+        int s = 0;
+        while (ks >= a.seg_nks[s]) { ks -= a.seg_nks[s]; ++s; }
+        const PackTile t = a.tile[slab * (a.rows / 32) + row / 32];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+        if (t.row0 >= 0 && s < a.slab_nseg[slab]) {
+            const HPackSrc src = a.set[t.set].seg[s];
+            const int r = t.row0 + (row & 31);
+            if (src.ptr && r < src.rows) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * (int)ks + 8 * kg + j;
+                    if (c < src.cols) v[j] = src.ptr[(long long)r * src.stride_r + (long long)c * src.stride_c] * src.scale;
+                }
+            }
+        }
+        char* d = a.wpacked + a.slab_woff[slab] + ks_abs * kstep_bytes + ((long long)kg * a.rows + row) * 16;
+        if (a.bf16) {
+            b8 hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
+            *reinterpret_cast<b8*>(d) = hi;
+        } else {
+            h8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hi[j] = (_Float16)v[j];
+            hi = pin(hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] = (_Float16)(v[j] - (float)hi[j]);
+            *reinterpret_cast<h8*>(d) = hi;
+            if (a.planes == 2) *reinterpret_cast<h8*>(d + plane_bytes) = lo;
+        }
+    }
+    const long long nb = (long long)a.nslab * a.rows;
+    if (idx < nb && a.bias) {
+        const int slab = (int)(idx / a.rows), rr = (int)(idx % a.rows);
+        const PackTile t = a.tile[slab * (a.rows / 32) + rr / 32];
+        float v = 0.0f;
+        if (t.row0 >= 0) {
+            const HPackSet& ps = a.set[t.set];
+            const int r = t.row0 + (rr & 31);
+            if (r < ps.bias_rows) {
+                if (ps.bias0) v += ps.bias0[r];
+                if (ps.bias1) v += ps.bias1[r];
+            }
+            v *= ps.bias_scale;
+        }
+        a.bias[a.slab_boff[slab] + rr] = v;
+    }
+}
+
+hipError_t launch_hpack(const HPackArgs& a, hipStream_t st) {
+    long long n = a.total_units;
+    const long long nb = (long long)a.nslab * a.rows;
+    if (nb > n) n = nb;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT, int P, bool BF, int EPI>
+__global__ __launch_bounds__(256, 1) void hgemm_kernel(const HGemmArgs a) {
+    constexpr int ROWS = 64 * MT;
+    constexpr int A_PLANE = 2 * ROWS * 16, B_PLANE = 2 * kHCol * 16;
+    constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;
+    constexpr int D = (131072 / STAGE) > 8 ? 8 : (131072 / STAGE);   // ring depth: 4 (f16x3, MT=4) ... 8
+    constexpr int A_PW = A_BYTES / 4096, B_PW = B_BYTES / 4096;       // 1 KiB pieces per wave per stage
+    constexpr int PW = A_PW + B_PW;
+    constexpr int INFLIGHT = (D - 2) * PW;                            // pieces allowed to be outstanding at the wait
+    static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
+    typedef typename HT<BF>::v8 V8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- XCD-aware work mapping (as series_gemm_kernel) ------------------------------------------------------
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int slab_i = local % a.nslab;
+    const int coltile = (local / a.nslab) * 8 + xcd;
+    if (coltile >= a.ncol) return;
+    const int b = coltile / a.tiles_per_row;
+    const int t0 = (coltile - b * a.tiles_per_row) * kHCol;
+    const HSlab sl = a.slab[slab_i];
+    const int ld = a.ld;
+
+    int nks = 0;
+    for (int s = 0; s < sl.nseg; ++s) nks += a.seg[s].nks;
+
+    // ---- staging state (all wave-uniform scalars) --------------------------------------------------------------
+    const char* a_src = a.wpacked + sl.woff;                 // stage ks of this slab: + ks * A_BYTES
+    int is_ks = 0;                                           // next k-step to issue
+    int is_seg = 0, is_left = a.seg[0].nks;
+    long long is_pstride = a.seg[0].pstride;
+    const long long unit0 = (long long)a.halo + t0 + 64 * wave;   // this wave's first time unit of the tile (+ tap offset)
+    const char* b_src = a.seg[0].base + (long long)b * a.seg[0].ustride + (unit0 + a.seg[0].off) * 16;
+    const unsigned lane16 = lane * 16u;
+
+    auto issue = [&](int slot) {
+        char* stage = lds + slot * STAGE;
+        const char* ap = a_src + (long long)is_ks * A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) WN_GLDS(ap + i * 4096 + lane16, stage + wave * 1024 + i * 4096);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+                WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + lane16,
+                        stage + A_BYTES + ((p * 2 + kg) * kHCol + 64 * wave) * 16);
+        // advance; past the last k-step the state stops and the surplus issues re-stage the last step (never read)
+        if (is_ks + 1 < nks) {
+            ++is_ks;
+            b_src += 2LL * ld * 16;
+            if (--is_left == 0) {
+                ++is_seg;
+                const HSeg ns = a.seg[is_seg];
+                is_left = ns.nks;
+                is_pstride = ns.pstride;
+                b_src = ns.base + (long long)b * ns.ustride + (unit0 + ns.off) * 16;
+            }
+        }
+    };
+
+    // ---- accumulators -----------------------------------------------------------------------------------------------
+    f32x16 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+
+    // ---- prologue: D-1 stages in flight -------------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) issue(s);
+
+    const unsigned a_rd = (unsigned)((h * ROWS + wm * 32 * MT + r) * 16);
+    const unsigned b_rd = (unsigned)(A_BYTES + (h * kHCol + wn * 128 + r) * 16);
+
+    int slot = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // this wave's pieces of stage ks have landed
+        __builtin_amdgcn_s_barrier();                                      // ... everyone's have; slot ks-1 is free
+        {
+            int wslot = slot - 1;
+            wslot = wslot < 0 ? D - 1 : wslot;
+            issue(wslot);                                                  // stage ks + D - 1 into the slot just freed
+        }
+        const char* st = lds + slot * STAGE;
+        V8 af[MT][P], bf[4][P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 512);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if constexpr (BF) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                } else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                    if constexpr (P == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][1], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the surplus stages before the epilogue's own loads/stores
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // C/D layout of the 32x32 tile: column = lane & 31, rows (q & 3) + 8 (q >> 2) + 4 h: registers 4i..4i+3 are four
+    // CONSECUTIVE channels 8i + 4h .. +3 of the tile = one 8-byte piece of the half-series unit (group, t).
+    const float osc = a.oscale;
+    unsigned ovf = 0;
+    const int rowbase = wm * 32 * MT;                      // first row of this wave inside the slab
+    if constexpr (EPI == HEPI_STORE) {
+        const HDst d = a.dst[sl.dst];
+        char* dbase = d.base + (long long)b * d.ustride + ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = rowbase + 32 * m + 8 * i;     // local row of the unit (multiple of 8)
+                const int ch = sl.row0 + lrow;
+                if (ch < d.cp) {
+                    float bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = a.bias ? a.bias[sl.boff + lrow + 4 * h + q] : 0.0f;
+                    char* prow = dbase + (long long)(ch >> 3) * ld * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (t0 + wn * 128 + 32 * n + r < a.L) {
+                            float v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = acc[m][n][4 * i + q] * osc + bv[q];
+                            store4<P, BF>(prow + n * 512, d.pstride, v, ovf);
+                        }
+                    }
+                }
+            }
+    } else if constexpr (EPI == HEPI_GATE) {
+        // tiles (2j, 2j+1) of a wave hold a and g of the same 32 channels
+        const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+#pragma unroll
+        for (int j = 0; j < MT / 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lch = wm * 16 * MT + 32 * j + 8 * i;          // local channel of the unit
+                const int ch = sl.row0 + lch;
+                if (ch < a.z.cp) {
+                    float ba[4], bg[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ba[q] = a.bias ? a.bias[sl.boff + rowbase + 32 * (2 * j) + 8 * i + 4 * h + q] : 0.0f;
+                        bg[q] = a.bias ? a.bias[sl.boff + rowbase + 32 * (2 * j + 1) + 8 * i + 4 * h + q] : 0.0f;
+                    }
+                    const long long o = (long long)(ch >> 3) * ld * 16 + col;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (t0 + wn * 128 + 32 * n + r < a.L) {
+                            float vt[4], vs[4], vz[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const bool valid = ch + 4 * h + q < a.gate_rows;   // pad channels stay exactly zero
+                                vt[q] = valid ? h_tanh(acc[2 * j][n][4 * i + q] * osc + ba[q]) : 0.0f;
+                                vs[q] = valid ? h_sigmoid(acc[2 * j + 1][n][4 * i + q] * osc + bg[q]) : 0.0f;
+                                vz[q] = vt[q] * vs[q];
+                            }
+                            const long long on = o + n * 512;
+                            store4<P, BF>(a.z.base + (long long)b * a.z.ustride + on, a.z.pstride, vz, ovf);
+                            if (a.ta.base) {
+                                store4<P, BF>(a.ta.base + (long long)b * a.ta.ustride + on, a.ta.pstride, vt, ovf);
+                                store4<P, BF>(a.sg.base + (long long)b * a.sg.ustride + on, a.sg.pstride, vs, ovf);
+                            }
+                        }
+                    }
+                }
+            }
+    } else if constexpr (EPI == HEPI_DGATE) {
+        const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = sl.row0 + rowbase + 32 * m + 8 * i;
+                if (ch < a.da.cp) {
+                    const long long o = (long long)(ch >> 3) * ld * 16 + col;
+                    float ta_[4][4], sg_[4][4];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {     // all eight (sixteen with lo planes) loads of the row group in flight together
+                        load4<P, BF>(a.ta.base + (long long)b * a.ta.ustride + o + n * 512, a.ta.pstride, ta_[n]);
+                        load4<P, BF>(a.sg.base + (long long)b * a.sg.ustride + o + n * 512, a.sg.pstride, sg_[n]);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (t0 + wn * 128 + 32 * n + r < a.L) {
+                            float va[4], vg[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float dz = acc[m][n][4 * i + q] * osc;
+                                const float t_ = ta_[n][q], s_ = sg_[n][q];
+                                va[q] = dz * s_ * (1.0f - t_ * t_);
+                                vg[q] = dz * t_ * s_ * (1.0f - s_);
+                            }
+                            store4<P, BF>(a.da.base + (long long)b * a.da.ustride + o + n * 512, a.da.pstride, va, ovf);
+                            store4<P, BF>(a.dg.base + (long long)b * a.dg.ustride + o + n * 512, a.dg.pstride, vg, ovf);
+                        }
+                    }
+                }
+            }
+    } else {   // HEPI_F32: dense fp32 [B][rows][L]
+        const float dsc = osc * (a.dyn_inv ? a.dyn_inv[0] : 1.0f);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int lrow = rowbase + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int row = sl.row0 + lrow;
+                if (row < a.out32_rows) {
+                    const float bv = a.bias ? a.bias[sl.boff + lrow] : 0.0f;
+                    float* prow = a.out32 + ((long long)b * a.out32_rows + row) * a.L + t0 + wn * 128 + r;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (t0 + wn * 128 + 32 * n + r < a.L) {
+                            float v = acc[m][n][q] * dsc + bv;
+                            if (a.out32_accum) v += prow[32 * n];
+                            prow[32 * n] = v;
+                        }
+                    }
+                }
+            }
+    }
+    if constexpr (!BF) {
+        if (ovf && a.flag) atomicOr(a.flag, 1u);
+    }
+}
+
+template <int MT, int P, bool BF>
+static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
+    switch (epi) {
+        case HEPI_STORE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
+        case HEPI_GATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_GATE>), dim3(grid), dim3(256), 0, st, a); break;
+        case HEPI_DGATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_DGATE>), dim3(grid), dim3(256), 0, st, a); break;
+        case HEPI_F32: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStream_t st) {
+    if (a_in.nslab <= 0 || a_in.B <= 0 || a_in.L <= 0) return hipSuccess;
+    HGemmArgs a = a_in;
+    a.tiles_per_row = (a.L + kHCol - 1) / kHCol;
+    a.ncol = a.B * a.tiles_per_row;
+    const unsigned grid = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));
+    if (MT == 4) {
+        if (prec == HP_F16X3) return launch_h<4, 2, false>(epi, a, grid, st);
+        if (prec == HP_F16) return launch_h<4, 1, false>(epi, a, grid, st);
+        if (prec == HP_BF16) return launch_h<4, 1, true>(epi, a, grid, st);
+    } else if (MT == 2) {
+        if (prec == HP_F16X3) return launch_h<2, 2, false>(epi, a, grid, st);
+        if (prec == HP_F16) return launch_h<2, 1, false>(epi, a, grid, st);
+        if (prec == HP_BF16) return launch_h<2, 1, true>(epi, a, grid, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace wn

@@ -1,0 +1,624 @@
+// C ABI of the half-precision-MFMA modes (f16x3 / f16 / bf16) of the residual-block path: shape checks, GEMM plans,
+// power-of-two scale bookkeeping and launches.  Host code only; kernels: wn_half.hip, wn_half_wgrad.hip, and the
+// split-K reduction of wn_wgrad.hip.
+//
+// Scales (all exact powers of two, so they never cost a rounding):
+//   residual stream x / r      stored as  value * kResidualScale (1/16): fp16 then holds |r| up to 1.0e6
+//   ta, sg, z                  stored as is (|.| <= 1)
+//   gradient series            stored as  value * s, s = a per-backward-call device scalar chosen by the host from max|d skips_sum|
+//   packed weights             256 * w / (scale of the segment's input), so an accumulator is 256 * true result
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wavenet_amd.h"
+#include "wn_half.h"
+
+using namespace wn;
+
+namespace wn { int hip_fail_shared(hipError_t e, const char* what); }
+
+namespace {
+
+#define WN_HIP(call, what)                                           \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return wn::hip_fail_shared(e__, what); \
+    } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int cp32(int c) { return rup(c, 32); }
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+bool half_prec(int p) { return p == WN_F16X3 || p == WN_F16 || p == WN_BF16; }
+
+int check_hlayout(int B, int L, int ld, int halo, int max_abs_off) {
+    if (B <= 0 || L <= 0) return WN_ERR_BAD_SHAPE;
+    if (halo < 0 || halo < max_abs_off) return WN_ERR_BAD_SHAPE;
+    if (ld < 2 * halo + rup(L, kHCol)) return WN_ERR_BAD_SHAPE;
+    return WN_OK;
+}
+
+int check_hblock(const wn_block_shape* s, int prec, int* off) {
+    if (!s) return WN_ERR_NULL;
+    if (!half_prec(prec)) return WN_ERR_UNSUPPORTED;
+    if (s->in_channels <= 0 || s->out_channels <= 0 || s->skip_rows <= 0 || s->dilation <= 0) return WN_ERR_BAD_SHAPE;
+    if (s->kernel_width < 1) return WN_ERR_BAD_SHAPE;
+    if (s->kernel_width > WN_MAX_TAPS) return WN_ERR_UNSUPPORTED;
+    if (s->in_channels > WN_MAX_CHANNELS || s->out_channels > WN_MAX_CHANNELS || s->skip_rows > WN_MAX_CHANNELS)
+        return WN_ERR_UNSUPPORTED;
+    wn_tap_offsets(s->kernel_width, s->dilation, s->causal, off);
+    int mx = 0;
+    for (int j = 0; j < s->kernel_width; ++j) mx = std::max(mx, std::abs(off[j]));
+    return check_hlayout(s->batch, s->length, s->ld, s->halo, mx);
+}
+
+// a half series as the kernels address it
+struct HView { char* base; long long ustride, pstride; int cp; };
+HView view(const void* p, int channels, int ld, int planes) {
+    HView v;
+    v.base = (char*)p;
+    v.cp = cp32(channels);
+    v.pstride = (long long)(v.cp / 8) * ld * 16;
+    v.ustride = v.pstride * planes;
+    return v;
+}
+HDst dst_of(const HView& v) { HDst d; d.base = v.base; d.ustride = v.ustride; d.pstride = v.pstride; d.cp = v.cp; d._pad = 0; return d; }
+
+// ---- GEMM plans -------------------------------------------------------------------------------------------------
+struct HPlan {
+    int MT = 4, rows = 256, nslab = 0, nseg = 0, planes = 1;
+    int seg_nks[kMaxSeg] = {0};
+    long long slab_woff[kHMaxSlab] = {0};
+    int slab_nseg[kHMaxSlab] = {0}, slab_row0[kHMaxSlab] = {0}, slab_boff[kHMaxSlab] = {0};
+    long long wbytes = 0;
+    int bfloats = 0;
+    void init(int out_rows, int planes_) {   // 256-row workgroup tiles for wide outputs, 128-row tiles otherwise
+        MT = out_rows > 128 ? 4 : 2;
+        rows = 64 * MT;
+        planes = planes_;
+    }
+    bool add_slab(int nseg_used, int row0) {
+        if (nslab >= kHMaxSlab) return false;
+        const int s = nslab++;
+        long long ks = 0;
+        for (int i = 0; i < nseg_used; ++i) ks += seg_nks[i];
+        slab_woff[s] = wbytes;
+        slab_nseg[s] = nseg_used;
+        slab_row0[s] = row0;
+        slab_boff[s] = bfloats;
+        wbytes += ks * planes * 2LL * rows * 16;
+        bfloats += rows;
+        return true;
+    }
+    size_t bytes() const { return align256((size_t)wbytes) + align256((size_t)bfloats * 4); }
+};
+
+struct HBlockPlan {
+    HPlan fa, fr, fs, ka, kb;
+    size_t off_fa = 0, off_fr = 0, off_fs = 0, off_ka = 0, off_kb = 0, total = 0;
+};
+
+HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
+    HBlockPlan p;
+    const int P = hp_planes(prec);
+    const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    {   // FA: [a ; g] interleaved in 32-channel tile pairs; K = k taps of x
+        HPlan& g = p.fa;
+        g.init(2 * Co, P);
+        g.nseg = k;
+        for (int j = 0; j < k; ++j) g.seg_nks[j] = cp32(Ci) / 16;
+        const int ch_per_slab = g.rows / 2;
+        for (int c0 = 0; c0 < Co; c0 += ch_per_slab) g.add_slab(k, c0);
+    }
+    {   // FR: r rows contract [z ; x]
+        HPlan& g = p.fr;
+        g.init(Co, P);
+        g.nseg = 2;
+        g.seg_nks[0] = cp32(Co) / 16;
+        g.seg_nks[1] = cp32(Ci) / 16;
+        for (int r0 = 0; r0 < Co; r0 += g.rows) g.add_slab(2, r0);
+    }
+    {   // FS: skip rows contract [z]
+        HPlan& g = p.fs;
+        g.init(Ms, P);
+        g.nseg = 1;
+        g.seg_nks[0] = cp32(Co) / 16;
+        for (int r0 = 0; r0 < Ms; r0 += g.rows) g.add_slab(1, r0);
+    }
+    {   // KA: dz rows (z channels) contract [dskip ; dr]
+        HPlan& g = p.ka;
+        g.init(Co, P);
+        g.nseg = 2;
+        g.seg_nks[0] = cp32(Ms) / 16;
+        g.seg_nks[1] = cp32(Co) / 16;
+        for (int r0 = 0; r0 < Co; r0 += g.rows) g.add_slab(2, r0);
+    }
+    {   // KB: dx rows (input channels) contract [da_0; dg_0; ...; dr]
+        HPlan& g = p.kb;
+        g.init(Ci, P);
+        g.nseg = 2 * k + 1;
+        for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
+        for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
+    }
+    p.off_fa = 0;
+    p.off_fr = p.off_fa + p.fa.bytes();
+    p.off_fs = p.off_fr + p.fr.bytes();
+    p.off_ka = p.off_fs + p.fs.bytes();
+    p.off_kb = p.off_ka + p.ka.bytes();
+    p.total = p.off_kb + p.kb.bytes();
+    return p;
+}
+
+void fill_hpack(HPackArgs& a, const HPlan& g, void* packed, size_t off, int prec) {
+    std::memset(&a, 0, sizeof(a));
+    a.nslab = g.nslab;
+    a.rows = g.rows;
+    a.planes = g.planes;
+    a.bf16 = prec == WN_BF16;
+    for (int i = 0; i < kMaxSeg; ++i) a.seg_nks[i] = g.seg_nks[i];
+    for (int i = 0; i < g.nslab; ++i) {
+        a.slab_woff[i] = g.slab_woff[i];
+        a.slab_nseg[i] = g.slab_nseg[i];
+        a.slab_boff[i] = g.slab_boff[i];
+    }
+    a.wpacked = (char*)packed + off;
+    a.bias = reinterpret_cast<float*>((char*)packed + off + align256((size_t)g.wbytes));
+    a.total_units = g.wbytes / (16 * g.planes);
+    a.set[0].bias_scale = a.set[1].bias_scale = 1.0f;
+}
+
+inline HPackSrc hsrc(const float* p, int rows, int cols, int sr, int sc, float scale) {
+    HPackSrc s; s.ptr = p; s.rows = rows; s.cols = cols; s.stride_r = sr; s.stride_c = sc; s.scale = scale; s._pad = 0; return s;
+}
+
+// tiles of a plain plan: row tile i of slab sl covers rows slab_row0 + 32 i
+void plain_tiles(HPackArgs& a, const HPlan& g, int valid_rows) {
+    for (int sl = 0; sl < g.nslab; ++sl)
+        for (int i = 0; i < g.rows / 32; ++i) {
+            const int row0 = g.slab_row0[sl] + 32 * i;
+            a.tile[sl * (g.rows / 32) + i].set = 0;
+            a.tile[sl * (g.rows / 32) + i].row0 = row0 < valid_rows ? row0 : -1;
+        }
+}
+
+void fill_hgemm(HGemmArgs& a, const HPlan& g, const void* packed, size_t off, int B, int L, int ld, int halo) {
+    std::memset(&a, 0, sizeof(a));
+    a.wpacked = (const char*)packed + off;
+    a.bias = reinterpret_cast<const float*>((const char*)packed + off + align256((size_t)g.wbytes));
+    a.nslab = g.nslab;
+    for (int i = 0; i < g.nslab; ++i) {
+        a.slab[i].woff = g.slab_woff[i];
+        a.slab[i].nseg = g.slab_nseg[i];
+        a.slab[i].row0 = g.slab_row0[i];
+        a.slab[i].boff = g.slab_boff[i];
+        a.slab[i].dst = 0;
+    }
+    a.B = B; a.L = L; a.ld = ld; a.halo = halo;
+    a.oscale = 1.0f / kWeightScale;
+}
+
+inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
+    a.seg[i].base = v.base; a.seg[i].ustride = v.ustride; a.seg[i].pstride = v.pstride; a.seg[i].off = off; a.seg[i].nks = nks;
+}
+
+// profiling classes shared with wn_api.hip (same table, same order)
+enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD };
+
+}  // namespace
+
+namespace wn {
+struct ProfScopeShared {   // implemented in wn_api.hip (HIP events on the launch stream when profiling is on)
+    void* impl;
+    ProfScopeShared(int kc, double flops, hipStream_t st);
+    ~ProfScopeShared();
+};
+}  // namespace wn
+
+// ==========================================================================================================================
+// C ABI
+// ==========================================================================================================================
+int wn_hseries_layout(int length, int max_abs_offset, int* ld, int* halo) {
+    if (!ld || !halo) return WN_ERR_NULL;
+    if (length <= 0 || max_abs_offset < 0) return WN_ERR_BAD_SHAPE;
+    *halo = max_abs_offset;
+    *ld = 2 * (*halo) + rup(length, kHCol);
+    return WN_OK;
+}
+
+size_t wn_hseries_bytes(int precision, int batch, int channels, int ld) {
+    if (!half_prec(precision) || batch <= 0 || channels <= 0 || ld <= 0) return 0;
+    return (size_t)batch * hp_planes(precision) * (cp32(channels) / 8) * (size_t)ld * 16;
+}
+
+float wn_hseries_residual_scale(void) { return kResidualScale; }
+
+int wn_hseries_load(int precision, const float* dense, void* series, int batch, int channels, int length, int ld, int halo,
+                    float scale, const float* dyn_scale, unsigned* overflow_flag, wn_stream_t stream) {
+    if (!half_prec(precision)) return WN_ERR_UNSUPPORTED;
+    if (!dense || !series) return WN_ERR_NULL;
+    int rc = check_hlayout(batch, length, ld, halo, 0);
+    if (rc != WN_OK) return rc;
+    if (channels <= 0 || channels > WN_MAX_CHANNELS) return WN_ERR_BAD_SHAPE;
+    HLoadArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.src = dense; a.dst = (char*)series; a.dyn_scale = dyn_scale; a.flag = overflow_flag; a.scale = scale;
+    a.B = batch; a.C = channels; a.L = length; a.G = cp32(channels) / 8; a.ld = ld; a.halo = halo;
+    a.planes = hp_planes(precision); a.bf16 = precision == WN_BF16;
+    wn::ProfScopeShared prof(KC_HLOAD, 0.0, (hipStream_t)stream);
+    WN_HIP(launch_hload(a, (hipStream_t)stream), "hload");
+    return WN_OK;
+}
+
+size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hblock(s, precision, off) != WN_OK) return 0;
+    return plan_hblock(s, precision).total;
+}
+
+int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hblock(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!p || !packed || !p->w_tanh || !p->w_sigmoid || !p->w_res || !p->w_skip || !p->w_proj) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HBlockPlan bp = plan_hblock(s, precision);
+    const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    const float WS = kWeightScale, RS = kResidualScale;
+    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
+    HPackArgs a;
+    {   // FA: gate rows; the input x is stored as x * RS
+        const HPlan& g = bp.fa;
+        fill_hpack(a, g, packed, bp.off_fa, precision);
+        for (int j = 0; j < k; ++j) {
+            a.set[0].seg[j] = hsrc(p->w_tanh + j, Co, Ci, Ci * k, k, WS / RS);
+            a.set[1].seg[j] = hsrc(p->w_sigmoid + j, Co, Ci, Ci * k, k, WS / RS);
+        }
+        a.set[0].bias0 = p->b_tanh; a.set[0].bias_rows = Co;
+        a.set[1].bias0 = p->b_sigmoid; a.set[1].bias_rows = Co;
+        const int tiles = g.rows / 32, per_wave = tiles / 2;   // a wave owns MT consecutive tiles = MT/2 (a, g) pairs
+        for (int sl = 0; sl < g.nslab; ++sl)
+            for (int i = 0; i < tiles; ++i) {
+                const int wm = i / per_wave, tw = i % per_wave;            // wave row, tile inside the wave
+                const int ch0 = g.slab_row0[sl] + wm * 16 * g.MT + 32 * (tw / 2);
+                a.tile[sl * tiles + i].set = tw & 1;
+                a.tile[sl * tiles + i].row0 = ch0 < Co ? ch0 : -1;
+            }
+        WN_HIP(launch_hpack(a, st), "hpack(gate)");
+    }
+    {   // FR: r = W_res z + W_proj x + b, stored as r * RS
+        const HPlan& g = bp.fr;
+        fill_hpack(a, g, packed, bp.off_fr, precision);
+        a.set[0].seg[0] = hsrc(p->w_res, Co, Co, Co, 1, WS);
+        a.set[0].seg[1] = hsrc(p->w_proj, Co, Ci, Ci, 1, WS / RS);
+        a.set[0].bias0 = p->b_res; a.set[0].bias1 = p->b_proj; a.set[0].bias_rows = Co; a.set[0].bias_scale = RS;
+        plain_tiles(a, g, Co);
+        WN_HIP(launch_hpack(a, st), "hpack(res)");
+    }
+    {   // FS: skip = W_skip z + b (fp32 out)
+        const HPlan& g = bp.fs;
+        fill_hpack(a, g, packed, bp.off_fs, precision);
+        a.set[0].seg[0] = hsrc(p->w_skip, Ms, Co, Co, 1, WS);
+        a.set[0].bias0 = p->b_skip; a.set[0].bias_rows = Ms;
+        plain_tiles(a, g, Ms);
+        WN_HIP(launch_hpack(a, st), "hpack(skip)");
+    }
+    {   // KA: rows = z channel c; seg0 cols = skip row m: w_skip[m][c]; seg1 cols = r row m: w_res[m][c]
+        const HPlan& g = bp.ka;
+        fill_hpack(a, g, packed, bp.off_ka, precision);
+        a.set[0].seg[0] = hsrc(p->w_skip, Co, Ms, 1, Co, WS);
+        a.set[0].seg[1] = hsrc(p->w_res, Co, Co, 1, Co, WS);
+        plain_tiles(a, g, Co);
+        a.bias = nullptr;
+        WN_HIP(launch_hpack(a, st), "hpack(dz)");
+    }
+    {   // KB: rows = input channel; cols = output channel
+        const HPlan& g = bp.kb;
+        fill_hpack(a, g, packed, bp.off_kb, precision);
+        for (int j = 0; j < k; ++j) {
+            a.set[0].seg[2 * j] = hsrc(p->w_tanh + j, Ci, Co, k, Ci * k, WS);
+            a.set[0].seg[2 * j + 1] = hsrc(p->w_sigmoid + j, Ci, Co, k, Ci * k, WS);
+        }
+        a.set[0].seg[2 * k] = hsrc(p->w_proj, Ci, Co, 1, Ci, WS);
+        plain_tiles(a, g, Ci);
+        a.bias = nullptr;
+        WN_HIP(launch_hpack(a, st), "hpack(dx)");
+    }
+    return WN_OK;
+}
+
+int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
+                      float* skip_dense, int skip_accumulate, void* ta, void* sg, void* z, unsigned* overflow_flag,
+                      wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hblock(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !x || !z) return WN_ERR_NULL;
+    if ((ta == nullptr) != (sg == nullptr)) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HBlockPlan bp = plan_hblock(s, precision);
+    const int P = hp_planes(precision);
+    const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    const double BL = (double)s->batch * s->length;
+    const HView vx = view(x, Ci, s->ld, P), vz = view(z, Co, s->ld, P);
+    HGemmArgs a;
+    {
+        const HPlan& g = bp.fa;
+        fill_hgemm(a, g, packed, bp.off_fa, s->batch, s->length, s->ld, s->halo);
+        for (int j = 0; j < k; ++j) set_hseg(a, j, vx, off[j], g.seg_nks[j]);
+        a.z = dst_of(vz);
+        if (ta) { a.ta = dst_of(view(ta, Co, s->ld, P)); a.sg = dst_of(view(sg, Co, s->ld, P)); }
+        a.gate_rows = Co;
+        a.flag = overflow_flag;
+        wn::ProfScopeShared prof(KC_HGATE, 2.0 * (2.0 * Co) * (double)(k * Ci) * BL, st);
+        WN_HIP(launch_hgemm(precision, g.MT, HEPI_GATE, a, st), "hgemm<gate>");
+    }
+    if (r_out) {
+        const HPlan& g = bp.fr;
+        fill_hgemm(a, g, packed, bp.off_fr, s->batch, s->length, s->ld, s->halo);
+        set_hseg(a, 0, vz, 0, g.seg_nks[0]);
+        set_hseg(a, 1, vx, 0, g.seg_nks[1]);
+        a.dst[0] = dst_of(view(r_out, Co, s->ld, P));
+        a.oscale = kResidualScale / kWeightScale;
+        a.flag = overflow_flag;
+        wn::ProfScopeShared prof(KC_HRES, 2.0 * Co * (double)(Co + Ci) * BL, st);
+        WN_HIP(launch_hgemm(precision, g.MT, HEPI_STORE, a, st), "hgemm<res>");
+    }
+    if (skip_dense) {
+        const HPlan& g = bp.fs;
+        fill_hgemm(a, g, packed, bp.off_fs, s->batch, s->length, s->ld, s->halo);
+        set_hseg(a, 0, vz, 0, g.seg_nks[0]);
+        a.out32 = skip_dense; a.out32_rows = Ms; a.out32_accum = skip_accumulate ? 1 : 0;
+        wn::ProfScopeShared prof(KC_HSKIP, 2.0 * Ms * (double)Co * BL, st);
+        WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<skip>");
+    }
+    return WN_OK;
+}
+
+int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                            const void* ta, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                            const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hblock(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !dskip || !ta || !sg || !da || !dg) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HBlockPlan bp = plan_hblock(s, precision);
+    const int P = hp_planes(precision);
+    const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    const double BL = (double)s->batch * s->length;
+    const HView vda = view(da, Co, s->ld, P), vdg = view(dg, Co, s->ld, P);
+    HGemmArgs a;
+    {   // dz = W_skip^T dskip + W_res^T dr ; da, dg
+        const HPlan& g = bp.ka;
+        fill_hgemm(a, g, packed, bp.off_ka, s->batch, s->length, s->ld, s->halo);
+        a.bias = nullptr;
+        set_hseg(a, 0, view(dskip, Ms, s->ld, P), 0, g.seg_nks[0]);
+        if (dr) set_hseg(a, 1, view(dr, Co, s->ld, P), 0, g.seg_nks[1]);
+        for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = dr ? 2 : 1;
+        a.ta = dst_of(view(ta, Co, s->ld, P)); a.sg = dst_of(view(sg, Co, s->ld, P));
+        a.da = dst_of(vda); a.dg = dst_of(vdg);
+        a.gate_rows = Co;
+        a.flag = overflow_flag;
+        wn::ProfScopeShared prof(KC_HDZ, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
+        WN_HIP(launch_hgemm(precision, g.MT, HEPI_DGATE, a, st), "hgemm<dz>");
+    }
+    if (dx || dx_dense) {
+        const HPlan& g = bp.kb;
+        fill_hgemm(a, g, packed, bp.off_kb, s->batch, s->length, s->ld, s->halo);
+        a.bias = nullptr;
+        for (int j = 0; j < k; ++j) {
+            set_hseg(a, 2 * j, vda, -off[j], g.seg_nks[2 * j]);
+            set_hseg(a, 2 * j + 1, vdg, -off[j], g.seg_nks[2 * j + 1]);
+        }
+        if (dr) set_hseg(a, 2 * k, view(dr, Co, s->ld, P), 0, g.seg_nks[2 * k]);
+        for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = 2 * k + (dr ? 1 : 0);
+        a.flag = overflow_flag;
+        wn::ProfScopeShared prof(KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
+        if (dx) {
+            a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
+            WN_HIP(launch_hgemm(precision, g.MT, HEPI_STORE, a, st), "hgemm<dx>");
+        } else {
+            a.out32 = dx_dense; a.out32_rows = Ci; a.out32_accum = 0; a.dyn_inv = dyn_inv_scale;
+            WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<dx dense>");
+        }
+    }
+    return WN_OK;
+}
+
+// ---- skips_sum of a whole stack ----------------------------------------------------------------------------------------
+namespace {
+int check_hskipsum(const wn_skipsum_shape* s, int prec) {
+    if (!s) return WN_ERR_NULL;
+    if (!half_prec(prec)) return WN_ERR_UNSUPPORTED;
+    if (s->nblocks < 1 || s->skip_rows <= 0) return WN_ERR_BAD_SHAPE;
+    if (s->nblocks > WN_MAX_STACK_GROUP || s->skip_rows > WN_MAX_CHANNELS) return WN_ERR_UNSUPPORTED;
+    for (int l = 0; l < s->nblocks; ++l) {
+        if (s->channels[l] <= 0) return WN_ERR_BAD_SHAPE;
+        if (s->channels[l] > WN_MAX_CHANNELS) return WN_ERR_UNSUPPORTED;
+    }
+    return check_hlayout(s->batch, s->length, s->ld, s->halo, 0);
+}
+HPlan plan_hskipsum(const wn_skipsum_shape* s, int prec) {
+    HPlan g;
+    g.init(s->skip_rows, hp_planes(prec));
+    g.nseg = s->nblocks;
+    for (int l = 0; l < s->nblocks; ++l) g.seg_nks[l] = cp32(s->channels[l]) / 16;
+    for (int r0 = 0; r0 < s->skip_rows; r0 += g.rows) g.add_slab(s->nblocks, r0);
+    return g;
+}
+}  // namespace
+
+size_t wn_hskipsum_packed_bytes(const wn_skipsum_shape* s, int precision) {
+    if (check_hskipsum(s, precision) != WN_OK) return 0;
+    return plan_hskipsum(s, precision).bytes();
+}
+
+int wn_hskipsum_pack(const wn_skipsum_shape* s, int precision, const float* const* w_skip, const float* bias_total, void* packed,
+                     wn_stream_t stream) {
+    int rc = check_hskipsum(s, precision);
+    if (rc != WN_OK) return rc;
+    if (!w_skip || !packed) return WN_ERR_NULL;
+    for (int l = 0; l < s->nblocks; ++l) if (!w_skip[l]) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HPlan g = plan_hskipsum(s, precision);
+    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
+    HPackArgs a;
+    fill_hpack(a, g, packed, 0, precision);
+    for (int l = 0; l < s->nblocks; ++l) a.set[0].seg[l] = hsrc(w_skip[l], s->skip_rows, s->channels[l], s->channels[l], 1, kWeightScale);
+    a.set[0].bias0 = bias_total; a.set[0].bias_rows = s->skip_rows;
+    plain_tiles(a, g, s->skip_rows);
+    WN_HIP(launch_hpack(a, st), "hpack(skipsum)");
+    return WN_OK;
+}
+
+int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* packed, const void* const* z, float* skip_dense,
+                        int accumulate, wn_stream_t stream) {
+    int rc = check_hskipsum(s, precision);
+    if (rc != WN_OK) return rc;
+    if (!packed || !z || !skip_dense) return WN_ERR_NULL;
+    for (int l = 0; l < s->nblocks; ++l) if (!z[l]) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HPlan g = plan_hskipsum(s, precision);
+    const int P = hp_planes(precision);
+    HGemmArgs a;
+    fill_hgemm(a, g, packed, 0, s->batch, s->length, s->ld, s->halo);
+    double ksum = 0;
+    for (int l = 0; l < s->nblocks; ++l) { set_hseg(a, l, view(z[l], s->channels[l], s->ld, P), 0, g.seg_nks[l]); ksum += s->channels[l]; }
+    a.out32 = skip_dense; a.out32_rows = s->skip_rows; a.out32_accum = accumulate ? 1 : 0;
+    wn::ProfScopeShared prof(KC_HSKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<skipsum>");
+    return WN_OK;
+}
+
+// ---- weight gradients ------------------------------------------------------------------------------------------------------
+namespace {
+struct HPairSpec { const void* A; int a_rows; const void* Bm; int b_rows; int off; int rowsum; float post;
+                   float* w; int sm, sn; float* b0; float* b1; };
+
+struct HWPlan {
+    int npair = 0, ntile_total = 0, nsplit = 1;
+    int Mp[kMaxPair], Np[kMaxPair], mt[kMaxPair], nt[kMaxPair], tile0[kMaxPair], rs_off[kMaxPair];
+    long long slab_off[kMaxPair];
+    long long slab_floats = 0;
+    int rs_floats = 0;
+    void add(int M, int N) {
+        const int T = 256, i = npair++;
+        mt[i] = cdiv(M, T); nt[i] = cdiv(N, T);
+        Mp[i] = mt[i] * T; Np[i] = nt[i] * T;
+        tile0[i] = ntile_total; ntile_total += mt[i] * nt[i];
+        slab_off[i] = slab_floats; slab_floats += (long long)Mp[i] * Np[i];
+        rs_off[i] = rs_floats; rs_floats += Mp[i];
+    }
+    void finish(int nstep) {
+        nsplit = std::max(1, 512 / std::max(1, ntile_total));
+        nsplit = std::min(nsplit, std::max(1, nstep / 8));      // at least a few k-steps per split
+        if (nsplit >= 16) nsplit = nsplit / 8 * 8;
+    }
+    bool xcd_map() const { return nsplit % 8 == 0; }
+    size_t bytes() const { return (size_t)nsplit * (size_t)(slab_floats + rs_floats) * 4; }
+};
+
+std::vector<HPairSpec> hblock_pairs(const wn_block_shape* s, const int* off, const void* x, const void* z, const void* da,
+                                    const void* dg, const void* dr, const void* dskip, const wn_block_params* g) {
+    const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    const float inv_rs = 1.0f / kResidualScale;
+    std::vector<HPairSpec> ps;
+    for (int j = 0; j < k; ++j) {
+        ps.push_back({da, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_tanh + j : nullptr, Ci * k, k, g ? g->b_tanh : nullptr, nullptr});
+        ps.push_back({dg, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_sigmoid + j : nullptr, Ci * k, k, g ? g->b_sigmoid : nullptr, nullptr});
+    }
+    ps.push_back({dskip, Ms, z, Co, 0, 1, 1.0f, g ? g->w_skip : nullptr, Co, 1, g ? g->b_skip : nullptr, nullptr});
+    if (dr) {
+        ps.push_back({dr, Co, z, Co, 0, 1, 1.0f, g ? g->w_res : nullptr, Co, 1, g ? g->b_res : nullptr, g ? g->b_proj : nullptr});
+        ps.push_back({dr, Co, x, Ci, 0, 0, inv_rs, g ? g->w_proj : nullptr, Ci, 1, nullptr, nullptr});
+    }
+    return ps;
+}
+
+int run_hwgrad(const std::vector<HPairSpec>& ps, int prec, int B, int L, int ld, int halo, const float* dyn_inv, void* workspace,
+               size_t workspace_bytes, bool dry, size_t* need, hipStream_t st) {
+    HWPlan wp;
+    for (const HPairSpec& p : ps) wp.add(p.a_rows, p.b_rows);
+    const int spr = cdiv(L, 16);
+    wp.finish(B * spr);
+    if (need) *need = wp.bytes();
+    if (dry || ps.empty()) return WN_OK;
+    if (!workspace) return WN_ERR_NULL;
+    if (workspace_bytes < wp.bytes() || (reinterpret_cast<uintptr_t>(workspace) & 15)) return WN_ERR_WORKSPACE;
+    const int P = hp_planes(prec);
+    HWgradArgs a;
+    std::memset(&a, 0, sizeof(a));
+    ReduceArgs r;
+    std::memset(&r, 0, sizeof(r));
+    double flops = 0;
+    for (int i = 0; i < wp.npair; ++i) {
+        HWgradPair& q = a.pair[i];
+        const HView va = view(ps[i].A, ps[i].a_rows, ld, P), vb = view(ps[i].Bm, ps[i].b_rows, ld, P);
+        // the kernel stages whole 256-channel tiles: the operands' padded channel counts must cover them
+        q.a_groups = va.cp / 8; q.b_groups = vb.cp / 8;
+        q.A = va.base; q.Bm = vb.base; q.a_ustride = va.ustride; q.a_pstride = va.pstride; q.b_ustride = vb.ustride; q.b_pstride = vb.pstride;
+        q.off = ps[i].off; q.mt = wp.mt[i]; q.nt = wp.nt[i]; q.tile0 = wp.tile0[i];
+        q.slab_off = wp.slab_off[i]; q.Mp = wp.Mp[i]; q.Np = wp.Np[i];
+        q.rowsum = ps[i].rowsum; q.rs_off = wp.rs_off[i];
+        ReduceDst& d = r.d[i];
+        d.w = ps[i].w; d.M = ps[i].a_rows; d.N = ps[i].b_rows; d.sm = ps[i].sm; d.sn = ps[i].sn;
+        d.slab_off = wp.slab_off[i]; d.Np = wp.Np[i];
+        d.b0 = ps[i].rowsum ? ps[i].b0 : nullptr; d.b1 = ps[i].rowsum ? ps[i].b1 : nullptr; d.rs_off = wp.rs_off[i];
+        d.post = ps[i].post;
+        flops += 2.0 * ps[i].a_rows * (double)ps[i].b_rows * (double)B * L;
+    }
+    a.npair = wp.npair; a.ntile_total = wp.ntile_total; a.nsplit = wp.nsplit; a.xcd_map = wp.xcd_map() ? 1 : 0;
+    a.B = B; a.L = L; a.ld = ld; a.halo = halo; a.steps_per_row = spr; a.nstep = B * spr;
+    a.slab = reinterpret_cast<float*>(workspace);
+    a.rowsum = a.slab + (size_t)wp.nsplit * wp.slab_floats;
+    a.slab_floats = wp.slab_floats; a.rs_floats = wp.rs_floats;
+    r.npair = wp.npair; r.nsplit = wp.nsplit; r.slab = a.slab; r.rowsum = a.rowsum;
+    r.slab_floats = wp.slab_floats; r.rs_floats = wp.rs_floats; r.dyn_inv = dyn_inv;
+    {
+        wn::ProfScopeShared prof(KC_HWGRAD, flops, st);
+        WN_HIP(launch_hwgrad(prec, a, st), "hwgrad");
+    }
+    {
+        wn::ProfScopeShared prof(KC_WGRAD_REDUCE, 0.0, st);
+        WN_HIP(launch_wgrad_reduce(r, st), "wgrad_reduce");
+    }
+    return WN_OK;
+}
+}  // namespace
+
+size_t wn_hblock_wgrad_workspace_bytes(const wn_block_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hblock(s, precision, off) != WN_OK) return 0;
+    static const float dummy = 0;
+    size_t need = 0;
+    for (int with_dr = 0; with_dr < 2; ++with_dr) {
+        std::vector<HPairSpec> ps = hblock_pairs(s, off, &dummy, &dummy, &dummy, &dummy, with_dr ? &dummy : nullptr, &dummy, nullptr);
+        size_t n = 0;
+        run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, nullptr, nullptr, 0, true, &n, nullptr);
+        need = std::max(need, n);
+    }
+    return need;
+}
+
+int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const void* x, const void* z, const void* da,
+                               const void* dg, const void* dr, const void* dskip, const wn_block_params* grads,
+                               const float* dyn_inv_scale, void* workspace, size_t workspace_bytes, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hblock(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!x || !z || !da || !dg || !dskip || !grads) return WN_ERR_NULL;
+    if (!grads->w_tanh || !grads->b_tanh || !grads->w_sigmoid || !grads->b_sigmoid || !grads->w_skip || !grads->b_skip)
+        return WN_ERR_NULL;
+    if (dr && (!grads->w_res || !grads->b_res || !grads->w_proj || !grads->b_proj)) return WN_ERR_NULL;
+    // the 256-channel staging tiles must lie inside the operands: channel counts are padded to 32, tiles to 256
+    std::vector<HPairSpec> ps = hblock_pairs(s, off, x, z, da, dg, dr, dskip, grads);
+    return run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, dyn_inv_scale, workspace, workspace_bytes, false,
+                      nullptr, (hipStream_t)stream);
+}

@@ -1,0 +1,230 @@
+// Weight gradients on the half-precision MFMAs (f16x3 / f16 / bf16 modes):
+//
+//     out_p[m][n] = sum_{b, t} A_p[b][m][t] * B_p[b][n][t + off_p]          (p = "pair", e.g. dW_tanh_j = sum da[t] x[t+off_j]^T)
+//
+// The contraction index is TIME, but the half-series layout (wn_half.h) keeps 8 CHANNELS of one time step together.
+// v_mfma_f32_32x32x16 wants, per lane, 8 consecutive k (= time steps) of one row (= channel): that transpose is done by
+// the hardware on the way out of LDS with ds_read_b64_tr_b16 (4 time rows x 16 channel columns per 16-lane group,
+// delivered column-major), so staging stays pure LDS-DMA of 16-byte units:
+//  * one stage = one k-step = 16 time steps of the A tile (64*WT channels) and of the B tile (64*WT channels);
+//    a 1 KiB DMA piece = 4 channel groups x 16 time steps = exactly one 32-channel MFMA tile of one k-step.
+//    Inside a piece the unit of (group g, time t) sits at 16*(t>>2) + 4*g + (t&3): the sixteen units one half-wave's
+//    transposed read touches (4 groups x 4 consecutive steps) are then 16 consecutive units = all 64 banks once.
+//    (The DMA source address is per lane, so this permutation costs nothing: each instruction still fetches whole
+//    128-byte lines -- 8 steps x 16 B of a group.)
+//  * workgroup = 4 waves (2 x 2), each wave a (32*WT)^2 tile of fp32 accumulators; split-K over time into slabs that
+//    wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no float atomics.
+//  * bias gradients (row sums of A over time) come from the A fragments already in registers: v_dot2c_f32_f16 against
+//    (1, 1) in the MFMAs' shadow, two of the wave's four row tiles per wave column.
+#include "wn_half.h"
+
+namespace wn {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
+                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+// 4 time rows x 16 channels of 16-bit elements per 16-lane group, transposed: lane i of the group gets channel i's four
+// steps (the builtin lets hipcc count the read and place its wait; an inline-asm read would need both done by hand)
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ u32x2 ds_read_tr16(const char* lds_ptr) {
+    const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(lds_ptr));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+template <bool BF>
+__device__ __forceinline__ float dot_ones(unsigned packed_pair, float acc) {
+    if constexpr (BF) {
+        const b2 one = {(__bf16)1.0f, (__bf16)1.0f};
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, packed_pair), one, acc, false);
+    } else {
+        const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, packed_pair), one, acc, false);
+    }
+}
+
+template <int WT, int P, bool BF>
+__global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
+    constexpr int CH = 64 * WT;                 // channels of the A tile and of the B tile
+    constexpr int T_PLANE = CH * 16 * 2;        // bytes of one operand's plane per k-step (CH channels x 16 steps x 2 B)
+    constexpr int A_BYTES = P * T_PLANE, STAGE = 2 * A_BYTES;
+    constexpr int D = (131072 / STAGE) > 8 ? 8 : (131072 / STAGE);
+    constexpr int PW = STAGE / 4096;            // 1 KiB pieces per wave per stage
+    constexpr int INFLIGHT = (D - 2) * PW;
+    static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    int split, tile;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        split = (local / a.ntile_total) * 8 + xcd;
+        tile = local % a.ntile_total;
+    } else {
+        split = blockIdx.x / a.ntile_total;
+        tile = blockIdx.x - split * a.ntile_total;
+    }
+    int p = 0;
+    while (p + 1 < a.npair && tile >= a.pair[p + 1].tile0) ++p;
+    const HWgradPair pr = a.pair[p];
+    const int tl = tile - pr.tile0;
+    const int tm = tl / pr.nt, tn = tl - tm * pr.nt;
+
+    // this split's range of k-steps (16 time steps of one utterance each)
+    const int s_begin = (int)((long long)a.nstep * split / a.nsplit);
+    const int s_end = (int)((long long)a.nstep * (split + 1) / a.nsplit);
+    const int nks = s_end - s_begin;
+
+    // ---- staging: each lane's source unit inside a piece (group gq, step tq), see the header comment ----------------
+    const int gq = (lane >> 2) & 3, tq = 4 * (lane >> 4) + (lane & 3);
+    const long long lane_src = ((long long)gq * a.ld + tq) * 16;
+    // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... of every plane of A, then of B
+    int is_step = s_begin;
+    auto issue = [&](int slot) {
+        char* stage = lds + slot * STAGE;
+        const int sb = is_step / a.steps_per_row;
+        const int st = (is_step - sb * a.steps_per_row) * 16;
+        const char* asrc = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16 + lane_src;
+        const char* bsrc = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16 + lane_src;
+#pragma unroll
+        for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+            for (int j = 0; j < CH / 32 / 4; ++j) {
+                const int piece = wave + 4 * j;
+                // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay
+                // inside the tensor by re-reading its last four groups
+                const int ga = min(tm * (CH / 8) + 4 * piece, pr.a_groups - 4), gb = min(tn * (CH / 8) + 4 * piece, pr.b_groups - 4);
+                WN_GLDS(asrc + pl * pr.a_pstride + (long long)ga * a.ld * 16, stage + pl * T_PLANE + piece * 1024);
+                WN_GLDS(bsrc + pl * pr.b_pstride + (long long)gb * a.ld * 16, stage + A_BYTES + pl * T_PLANE + piece * 1024);
+            }
+        if (is_step + 1 < s_end) ++is_step;
+    };
+
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+    float rs[WT / 2];
+#pragma unroll
+    for (int m = 0; m < WT / 2; ++m) rs[m] = 0.0f;
+
+    if (nks > 0) {
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) issue(s);
+    }
+
+    // transposed-read address of this lane inside a piece: 16-lane group sg -> channels 16 sg.., lane 4q+pp -> step q, channels 4pp..
+    const int sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned rd = (unsigned)((32 * h + 4 * (2 * sg + (pp >> 1)) + q4) * 16 + 8 * (pp & 1));
+    const bool do_rs = pr.rowsum != 0;
+
+    int slot = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            int wslot = slot - 1;
+            wslot = wslot < 0 ? D - 1 : wslot;
+            issue(wslot);
+        }
+        const char* sa = lds + slot * STAGE + rd + (wm * WT) * 1024;
+        const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WT) * 1024;
+        u32x4 af[WT][P], bf[WT][P];
+#pragma unroll
+        for (int pl = 0; pl < P; ++pl) {
+#pragma unroll
+            for (int m = 0; m < WT; ++m) {
+                const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + 256);
+                af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+            for (int n = 0; n < WT; ++n) {
+                const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + 256);
+                bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < WT; ++m)
+#pragma unroll
+            for (int n = 0; n < WT; ++n) {
+                if constexpr (BF) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
+                } else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    if constexpr (P == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        if (do_rs) {   // row sums of A for two of this wave's row tiles (the other wave column takes the other two)
+#pragma unroll
+            for (int mm = 0; mm < WT / 2; ++mm) {
+                const int m = wn * (WT / 2) + mm;   // wave-uniform, but must be a compile-time register index:
+#pragma unroll
+                for (int mc = 0; mc < WT; ++mc)
+                    if (mc == m) {
+#pragma unroll
+                        for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) rs[mm] = dot_ones<BF>(af[mc][pl][w], rs[mm]);
+                    }
+            }
+        }
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- write this split's partial tile -----------------------------------------------------------------------------
+    float* out = a.slab + (long long)split * a.slab_floats + pr.slab_off;
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = tm * CH + wm * 32 * WT + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * h;
+            float* prow = out + (long long)row * pr.Np + tn * CH + wn * 32 * WT + r;
+#pragma unroll
+            for (int n = 0; n < WT; ++n) prow[32 * n] = acc[m][n][q];
+        }
+    if (do_rs && tn == 0) {
+#pragma unroll
+        for (int mm = 0; mm < WT / 2; ++mm) {
+            const float tot = rs[mm] + __shfl_xor(rs[mm], 32);
+            const int row = tm * CH + wm * 32 * WT + 32 * (wn * (WT / 2) + mm) + r;
+            if (h == 0) a.rowsum[(long long)split * a.rs_floats + pr.rs_off + row] = tot;
+        }
+    }
+}
+
+hipError_t launch_hwgrad(int prec, const HWgradArgs& a, int WT, hipStream_t st);
+
+template <int WT>
+static hipError_t launch_hw(int prec, const HWgradArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)(a.ntile_total * a.nsplit)), block(256);
+    if (prec == HP_F16X3) hipLaunchKernelGGL((hwgrad_kernel<WT, 2, false>), grid, block, 0, st, a);
+    else if (prec == HP_F16) hipLaunchKernelGGL((hwgrad_kernel<WT, 1, false>), grid, block, 0, st, a);
+    else if (prec == HP_BF16) hipLaunchKernelGGL((hwgrad_kernel<WT, 1, true>), grid, block, 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_hwgrad(int prec, const HWgradArgs& a, hipStream_t st) {
+    if (a.ntile_total <= 0 || a.nsplit <= 0) return hipSuccess;
+    return launch_hw<4>(prec, a, st);
+}
+
+}  // namespace wn

@@ -134,13 +134,15 @@ struct ReduceDst {
     int M, N, sm, sn;
     long long slab_off; int Np;
     float* b0; float* b1; // row-sum destinations (nullable)
-    int rs_off; int _pad;
+    int rs_off;
+    float post;           // the matrix is multiplied by this on the way out (1 in the fp32 path; 1/input scale in the half path)
 };
 struct ReduceArgs {
     ReduceDst d[kMaxPair];
     int npair, nsplit;
     const float* slab; const float* rowsum;
     long long slab_floats; int rs_floats;
+    const float* dyn_inv; // optional device scalar multiplied into every output (1 / dynamic gradient scale of the half path)
 };
 
 // launchers (defined in the .hip files)

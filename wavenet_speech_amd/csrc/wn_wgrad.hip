@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
     const int p = blockIdx.y;
     const ReduceDst d = a.d[p];
+    const float dyn = a.dyn_inv ? a.dyn_inv[0] : 1.0f;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int nq = (d.N + 3) >> 2;   // each thread sums four consecutive columns (16-byte loads; the slab is padded to Np)
     if (idx < (long long)d.M * nq && d.w) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
         for (; s < a.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (long long)s * a.slab_floats);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (n + j < d.N) d.w[(long long)m * d.sm + (long long)(n + j) * d.sn] = v[j];
+            if (n + j < d.N) d.w[(long long)m * d.sm + (long long)(n + j) * d.sn] = v[j] * (d.post * dyn);
     }
     if (idx < d.M && (d.b0 || d.b1)) {
         const float* src = a.rowsum + d.rs_off + idx;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
             for (int u = 0; u < 24; ++u) v += t[u];
         }
         for (; s < a.nsplit; ++s) v += src[(long long)s * a.rs_floats];
+        v *= dyn;
         if (d.b0) d.b0[idx] = v;
         if (d.b1) d.b1[idx] = v;
     }

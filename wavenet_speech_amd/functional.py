@@ -278,7 +278,7 @@ def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None):
     precision: "f32" (exact fp32 MFMA, default) or one of the half-precision MFMA modes of functional_half."""
     if precision != "f32":
         from . import functional_half
-        return functional_half.residual_stack(x, specs, flat_params, precision)
+        return functional_half.residual_stack(x, specs, flat_params, precision, pack_cache)
     return _ResidualStackFn.apply(x, tuple(specs), torch.is_grad_enabled(), pack_cache, *flat_params)
 
 

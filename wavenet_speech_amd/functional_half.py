@@ -1,0 +1,207 @@
+"""
+Host side of the half-precision-MFMA modes of the residual stack ("f16x3", "f16", "bf16"): the same
+torch.autograd.Function shape as functional._ResidualStackFn, driving the wn_h* entry points of the C ABI.
+
+    f16x3  operands split into two fp16 planes, three MFMAs per product, fp32 accumulate: fp32-equivalent results
+           (same 1e-4 parity bar as the fp32 path) at 3/16 of the fp32 MFMA cost
+    f16 / bf16   plain half storage + MFMA, fp32 accumulate (BASELINE configs[4] / configs[1]); their error is the
+           storage format's (measured in tests/test_gpu_half.py), far from 1e-4 through 30 blocks
+
+Activations live in the "half series" layout of include/wavenet_amd.h; torch supplies device memory (series.Lease with a
+half dtype), the stream and autograd bookkeeping.  There is no CPU path.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from .functional import PARAMS_PER_BLOCK, _on_device_of_first_tensor, _p, _params_struct, _prep_params, _require_device, _stream
+from .series import Lease
+
+GRAD_TARGET = 64.0   # the cotangent is scaled by a power of two so that max|d skips_sum| lands in [32, 64]
+
+
+def _cp32(c):
+    return (c + 31) // 32 * 32
+
+
+class HalfLayout(object):
+    """row geometry of the half series of one call (wn_hseries_layout)"""
+
+    def __init__(self, length, max_abs_offset):
+        self.length = int(length)
+        self.ld, self.halo = _lib.hseries_layout(self.length, int(max_abs_offset))
+
+    def key(self):
+        return ("half", self.length, self.ld, self.halo)
+
+
+class _Mode(object):
+    def __init__(self, precision):
+        self.name = precision
+        self.code = _lib.PRECISIONS[precision]
+        self.planes = 2 if precision == "f16x3" else 1
+        self.dtype = torch.bfloat16 if precision == "bf16" else torch.float16
+
+
+def _hlease(mode, batch, channels, layout, device):
+    g = _cp32(channels) // 8
+    return Lease(batch, channels, layout, device, dtype=mode.dtype, rows=mode.planes * g, pitch=layout.ld * 8)
+
+
+def _shape(spec, batch, layout):
+    return _lib.BlockShape(batch, layout.length, spec.ci, spec.co, spec.ms, spec.k, spec.d, int(spec.causal),
+                           layout.ld, layout.halo)
+
+
+def _check_overflow(flag, what):
+    if flag is not None and int(flag.item()):
+        raise RuntimeError("wavenet_speech_amd: fp16 overflow in the %s of the half-precision stack (a value beyond +-65504 "
+                           "after the built-in 1/16 residual scaling); use precision='f32' or 'bf16' for this model" % what)
+
+
+def _load(lib, mode, dense, lease, layout, scale, dyn, flag):
+    B, C, L = dense.shape
+    _lib.check(lib.wn_hseries_load(mode.code, _p(dense), _p(lease), B, C, L, layout.ld, layout.halo, ctypes.c_float(scale),
+                                   _p(dyn), _p(flag), _stream()), "wn_hseries_load")
+
+
+class _HalfStackFn(torch.autograd.Function):
+    """skips_sum of a stack (modules/wavenet.py:98-100 with folded bottlenecks) on the half-precision MFMAs"""
+
+    @staticmethod
+    @_on_device_of_first_tensor
+    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, *flat):
+        lib = _lib.load()
+        _require_device(x, "input")
+        n = len(specs)
+        assert len(flat) == n * PARAMS_PER_BLOCK
+        B, C0, L = x.shape
+        if C0 != specs[0].ci:
+            raise RuntimeError("wavenet_speech_amd: input has %d channels, first block expects %d" % (C0, specs[0].ci))
+        for l in range(1, n):
+            if specs[l].ci != specs[l - 1].co:
+                raise RuntimeError("wavenet_speech_amd: block %d expects %d input channels but block %d produces %d"
+                                   % (l, specs[l].ci, l - 1, specs[l - 1].co))
+        dev = x.device
+        layout = HalfLayout(L, max(s.reach() for s in specs))
+        training = bool(grad_enabled) and any(ctx.needs_input_grad)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
+        rs = float(lib.wn_hseries_residual_scale())
+        cur = _hlease(mode, B, C0, layout, dev)
+        _load(lib, mode, x.detach().contiguous(), cur, layout, rs, None, flag)
+        ms = specs[0].ms
+        S = torch.empty(B, ms, L, dtype=torch.float32, device=dev)
+        saved, skip_w, skip_b = [], [], []
+        zbuf = None
+        for l, spec in enumerate(specs):
+            if spec.ms != ms:
+                raise RuntimeError("wavenet_speech_amd: all blocks of a stack must share out_dim")
+            shape = _shape(spec, B, layout)
+            params = _prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec)
+            packed = pack_cache.get(l, layout, B) if (pack_cache is not None and not training) else None
+            if packed is None:
+                nbytes = lib.wn_hblock_packed_bytes(ctypes.byref(shape), mode.code)
+                if nbytes == 0:
+                    _lib.check(-1, "wn_hblock_packed_bytes")
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                ps = _params_struct(params)
+                _lib.check(lib.wn_hblock_pack(ctypes.byref(shape), mode.code, ctypes.byref(ps), _p(packed), _stream()),
+                           "wn_hblock_pack")
+                if pack_cache is not None and not training:
+                    pack_cache.put(l, layout, B, packed)
+            r = _hlease(mode, B, spec.co, layout, dev) if l + 1 < n else None
+            if training:
+                ta, sg, z = (_hlease(mode, B, spec.co, layout, dev) for _ in range(3))
+            else:
+                ta = sg = None
+                if zbuf is None or zbuf.channels != spec.co:
+                    zbuf = _hlease(mode, B, spec.co, layout, dev)
+                z = zbuf
+            _lib.check(lib.wn_hblock_forward(ctypes.byref(shape), mode.code, _p(packed), _p(cur), _p(r),
+                                             None if training else _p(S), 0 if l == 0 else 1, _p(ta), _p(sg), _p(z),
+                                             _p(flag), _stream()), "wn_hblock_forward")
+            if training:
+                saved.append((cur, ta, sg, z, packed, shape))
+                skip_w.append(params[6])
+                skip_b.append(params[7])
+            cur = r
+        if training:
+            bias_total = torch.stack(skip_b).sum(0).contiguous()
+            G = _lib.MAX_STACK_GROUP
+            for g0 in range(0, n, G):
+                idx = range(g0, min(g0 + G, n))
+                m = len(idx)
+                shape = _lib.SkipSumShape(B, L, ms, m, layout.ld, layout.halo)
+                for i, l in enumerate(idx):
+                    shape.channels[i] = specs[l].co
+                nbytes = lib.wn_hskipsum_packed_bytes(ctypes.byref(shape), mode.code)
+                if nbytes == 0:
+                    _lib.check(-1, "wn_hskipsum_packed_bytes")
+                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                wptrs = (ctypes.c_void_p * m)(*[skip_w[l].data_ptr() for l in idx])
+                zptrs = (ctypes.c_void_p * m)(*[saved[l][3].ptr for l in idx])
+                _lib.check(lib.wn_hskipsum_pack(ctypes.byref(shape), mode.code, wptrs, _p(bias_total) if g0 == 0 else None,
+                                                _p(packed), _stream()), "wn_hskipsum_pack")
+                _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
+                                                   0 if g0 == 0 else 1, _stream()), "wn_hskipsum_forward")
+        _check_overflow(flag, "forward pass")
+        ctx.specs, ctx.saved, ctx.layout, ctx.batch, ctx.mode = specs, saved, layout, B, mode
+        ctx.param_shapes = [tuple(t.shape) for t in flat]
+        return S
+
+    @staticmethod
+    @once_differentiable
+    @_on_device_of_first_tensor
+    def backward(ctx, d_skips):
+        lib = _lib.load()
+        specs, layout, B, mode = ctx.specs, ctx.layout, ctx.batch, ctx.mode
+        dev = d_skips.device
+        d_skips = d_skips.contiguous()
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
+        # dynamic power-of-two scale of the whole gradient domain, computed on the device (no host sync)
+        amax = d_skips.abs().amax().clamp_min(1e-30)
+        dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
+        dyn_inv = (1.0 / dyn).contiguous()
+        dS = _hlease(mode, B, specs[0].ms, layout, dev)
+        _load(lib, mode, d_skips, dS, layout, 1.0, dyn, flag)
+        dr = None
+        dx0 = None
+        grads_flat = [None] * (len(specs) * PARAMS_PER_BLOCK)
+        for l in range(len(specs) - 1, -1, -1):
+            spec = specs[l]
+            x, ta, sg, z, packed, shape = ctx.saved[l]
+            da, dg = _hlease(mode, B, spec.co, layout, dev), _hlease(mode, B, spec.co, layout, dev)
+            dx = dxd = None
+            if l > 0:
+                dx = _hlease(mode, B, spec.ci, layout, dev)
+            elif ctx.needs_input_grad[0]:
+                dxd = dx0 = torch.empty(B, spec.ci, layout.length, dtype=torch.float32, device=dev)
+            _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(ta), _p(sg),
+                                                   _p(da), _p(dg), _p(dx), _p(dxd), _p(dyn_inv), _p(flag), _stream()),
+                       "wn_hblock_backward_data")
+            k = spec.k
+            shapes = [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
+                      (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]
+            unused = (4, 5, 8, 9) if dr is None else ()
+            grads = [None if i in unused else torch.empty(s, dtype=torch.float32, device=dev) for i, s in enumerate(shapes)]
+            ws_bytes = lib.wn_hblock_wgrad_workspace_bytes(ctypes.byref(shape), mode.code)
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            gs = _params_struct(grads)
+            _lib.check(lib.wn_hblock_backward_weights(ctypes.byref(shape), mode.code, _p(x), _p(z), _p(da), _p(dg), _p(dr),
+                                                      _p(dS), ctypes.byref(gs), _p(dyn_inv), _p(ws), ws_bytes, _stream()),
+                       "wn_hblock_backward_weights")
+            grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
+            dr = dx
+            ctx.saved[l] = None
+        _check_overflow(flag, "backward pass")
+        grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
+        return (dx0, None, None, None, None) + tuple(grads_flat)
+
+
+def residual_stack(x, specs, flat_params, precision, pack_cache=None):
+    if precision not in ("f16x3", "f16", "bf16"):
+        raise ValueError("unknown precision %r" % (precision,))
+    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, *flat_params)
