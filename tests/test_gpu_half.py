@@ -136,3 +136,38 @@ def test_fp16_overflow_is_loud():
         net(x)
     W.set_precision(net, "bf16")
     assert bool(torch.isfinite(net(x)).all())
+
+
+def test_f16x3_cfg3_one_utterance_vs_oracle():
+    """the full configs[2] utterance (256 ch x 30 blocks x 16000 steps) at the fp32 path's own 1e-4 bar"""
+    from tests.test_gpu_fullsize import _layers, _onehot, _wavenet
+    c, L = 256, 16000
+    layers = _layers(c, 3)
+    net = _wavenet(c, layers)
+    x, cot = _onehot(1, c, L, 1)
+    errs = _run(net, x, cot, layers, "f16x3", TOL)
+    assert errs["forward"] < 2e-5
+
+
+def test_f16x3_survives_the_reference_init_at_30_blocks():
+    """reference init: the residual stream reaches ~7e4 and gradients grow ~2^15 on the way back -- inside the range the
+    built-in power-of-two scales leave (no overflow error).  This map is ill-conditioned (two CPU fp32 summation orders
+    differ by 4.5e-4 themselves); hi+lo carries 22-23 significant bits against fp32's 24, and the
+    amplification multiplies that: the f16x3 result is allowed 10x the CPU fp32 path's own distance from fp64."""
+    from tests.test_gpu_fullsize import _layers, _onehot, _wavenet
+    c, L = 256, 4000
+    layers = _layers(c, 3)
+    net = _wavenet(c, layers, seed=7, conditioned=False)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, cot = _onehot(1, c, L, 8)
+    with torch.no_grad():
+        y64 = O.wavenet(x.double(), {k: v.double() for k, v in sd.items()}, layers, False, impl="taps")
+        y_cpu = O.wavenet(x, sd, layers, False, impl="aten")
+    net = net.to(DEV)
+    W.set_precision(net, "f16x3")
+    y = net(x.to(DEV))
+    (y * cot.to(DEV)).sum().backward()            # must not raise
+    e_cpu, e_hip = O.rel_err(y_cpu.double(), y64), O.rel_err(y.detach().cpu().double(), y64)
+    print("reference init, 30 blocks: CPU fp32 vs fp64 %.2e, f16x3 vs fp64 %.2e" % (e_cpu, e_hip))
+    assert e_hip < max(TOL, 10.0 * e_cpu)
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)

@@ -225,12 +225,16 @@ hipError_t launch_hpack(const HPackArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------------------------
+// MT=4: 256-row tiles, one workgroup per CU (all 512 registers of a lane, the whole 160 KiB of LDS: a 5-deep ring at
+// f16x3).  MT=2: 128-row tiles sized for TWO workgroups per CU (<= 256 registers, <= 80 KiB): the epilogue of one
+// workgroup -- an HBM-bound burst of stores with no MFMA in it -- then overlaps the other's K loop.
 template <int MT, int P, bool BF, int EPI>
-__global__ __launch_bounds__(256, 1) void hgemm_kernel(const HGemmArgs a) {
+__global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemmArgs a) {
     constexpr int ROWS = 64 * MT;
     constexpr int A_PLANE = 2 * ROWS * 16, B_PLANE = 2 * kHCol * 16;
     constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;
-    constexpr int D = (131072 / STAGE) > 8 ? 8 : (131072 / STAGE);   // ring depth: 4 (f16x3, MT=4) ... 8
+    constexpr int LDS_BUDGET = MT == 4 ? 163840 : 81920;
+    constexpr int D = (LDS_BUDGET / STAGE) > 8 ? 8 : (LDS_BUDGET / STAGE);   // ring depth: 5 (f16x3, MT=4) ... 8
     constexpr int A_PW = A_BYTES / 4096, B_PW = B_BYTES / 4096;       // 1 KiB pieces per wave per stage
     constexpr int PW = A_PW + B_PW;
     constexpr int INFLIGHT = (D - 2) * PW;                            // pieces allowed to be outstanding at the wait

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,7 +80,9 @@ struct HPlan {
     long long wbytes = 0;
     int bfloats = 0;
     void init(int out_rows, int planes_) {   // 256-row workgroup tiles for wide outputs, 128-row tiles otherwise
+        static const int force = getenv("WN_HALF_MT") ? atoi(getenv("WN_HALF_MT")) : 0;   // measurement knob
         MT = out_rows > 128 ? 4 : 2;
+        if (force == 2 || force == 4) MT = force;
         rows = 64 * MT;
         planes = planes_;
     }
@@ -227,7 +230,7 @@ struct ProfScopeShared {   // implemented in wn_api.hip (HIP events on the launc
 int wn_hseries_layout(int length, int max_abs_offset, int* ld, int* halo) {
     if (!ld || !halo) return WN_ERR_NULL;
     if (length <= 0 || max_abs_offset < 0) return WN_ERR_BAD_SHAPE;
-    *halo = max_abs_offset;
+    *halo = rup(max_abs_offset, 8);   // t = 0 then starts a 128-byte line of every channel group
     *ld = 2 * (*halo) + rup(length, kHCol);
     return WN_OK;
 }

@@ -8,10 +8,10 @@
 // delivered column-major), so staging stays pure LDS-DMA of 16-byte units:
 //  * one stage = one k-step = 16 time steps of the A tile (64*WT channels) and of the B tile (64*WT channels);
 //    a 1 KiB DMA piece = 4 channel groups x 16 time steps = exactly one 32-channel MFMA tile of one k-step.
-//    Inside a piece the unit of (group g, time t) sits at 16*(t>>2) + 4*g + (t&3): the sixteen units one half-wave's
-//    transposed read touches (4 groups x 4 consecutive steps) are then 16 consecutive units = all 64 banks once.
-//    (The DMA source address is per lane, so this permutation costs nothing: each instruction still fetches whole
-//    128-byte lines -- 8 steps x 16 B of a group.)
+//    Inside a piece the unit of (group g, time t) sits at 32*(t>>3) + 8*g + ((t&7) ^ 4*(g>>1)): eight consecutive lanes
+//    of the DMA fetch one whole 128-byte line (8 steps of a group), and the sixteen units one half-wave's transposed read
+//    touches (4 groups x 4 consecutive steps) fall into 16 different 16-byte slots = all 64 banks once.
+//    (The DMA source address is per lane, so the permutation costs nothing.)
 //  * workgroup = 4 waves (2 x 2), each wave a (32*WT)^2 tile of fp32 accumulators; split-K over time into slabs that
 //    wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no float atomics.
 //  * bias gradients (row sums of A over time) come from the A fragments already in registers: v_dot2c_f32_f16 against
@@ -28,8 +28,19 @@ typedef __bf16 b2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#define WN_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
-                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+// LDS-DMA issued from inline asm, NOT through __builtin_amdgcn_global_load_lds: with the builtin hipcc (ROCm 7.2) knows an
+// LDS write is pending on the vm counter and, because it cannot tell which LDS bytes __builtin_amdgcn_ds_read_tr16_b64 reads,
+// puts `s_waitcnt vmcnt(0)` in front of the first transposed read of every k-step -- i.e. it waits for the prefetches just
+// issued and the ring degenerates to synchronous staging (measured: SQ_WAIT_ANY 45 % of the wave cycles, 0.85 ms per launch).
+// Hidden in asm the DMAs are counted by hand: one `s_waitcnt vmcnt(N)` + s_barrier per k-step (see the loop).  M0 (the LDS
+// destination base) is compiler-reserved: it is saved, set and restored inside the one statement.
+__device__ __forceinline__ void glds16(const char* gsrc, const char* lds_dst) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#define WN_GLDS(gp, lp) glds16((gp), (lp))
 
 // 4 time rows x 16 channels of 16-bit elements per 16-lane group, transposed: lane i of the group gets channel i's four
 // steps (the builtin lets hipcc count the read and place its wait; an inline-asm read would need both done by hand)
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     constexpr int CH = 64 * WT;                 // channels of the A tile and of the B tile
     constexpr int T_PLANE = CH * 16 * 2;        // bytes of one operand's plane per k-step (CH channels x 16 steps x 2 B)
     constexpr int A_BYTES = P * T_PLANE, STAGE = 2 * A_BYTES;
-    constexpr int D = (131072 / STAGE) > 8 ? 8 : (131072 / STAGE);
+    constexpr int D = (163840 / STAGE) > 8 ? 8 : (163840 / STAGE);   // 5 stages at f16x3: the whole LDS
     constexpr int PW = STAGE / 4096;            // 1 KiB pieces per wave per stage
     constexpr int INFLIGHT = (D - 2) * PW;
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
@@ -87,7 +98,10 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int nks = s_end - s_begin;
 
     // ---- staging: each lane's source unit inside a piece (group gq, step tq), see the header comment ----------------
-    const int gq = (lane >> 2) & 3, tq = 4 * (lane >> 4) + (lane & 3);
+    // unit u = lane of a piece holds (group g, step t) with u = 32 (t >> 3) + 8 g + ((t & 7) ^ 4 (g >> 1)): eight
+    // consecutive lanes fetch one whole 128-byte line (8 steps of a group), and the XOR spreads groups g and g + 2 over
+    // different banks for the transposed reads
+    const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
     const long long lane_src = ((long long)gq * a.ld + tq) * 16;
     // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... of every plane of A, then of B
     int is_step = s_begin;
@@ -129,7 +143,9 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
 
     // transposed-read address of this lane inside a piece: 16-lane group sg -> channels 16 sg.., lane 4q+pp -> step q, channels 4pp..
     const int sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
-    const unsigned rd = (unsigned)((32 * h + 4 * (2 * sg + (pp >> 1)) + q4) * 16 + 8 * (pp & 1));
+    const int gr = 2 * sg + (pp >> 1);   // group of this lane's channels inside the 32-channel piece
+    const unsigned rd = (unsigned)((32 * h + 8 * gr + (q4 ^ (4 * (gr >> 1)))) * 16 + 8 * (pp & 1));   // steps 8h + q4; +4: XOR 4 units
+    const int hi_off = (gr >> 1) ? -64 : 64;   // steps 8h + 4 + q4: the unit index with bit 2 flipped
     const bool do_rs = pr.rowsum != 0;
 
     int slot = 0;
@@ -148,12 +164,12 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
         for (int pl = 0; pl < P; ++pl) {
 #pragma unroll
             for (int m = 0; m < WT; ++m) {
-                const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + 256);
+                const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
                 af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
 #pragma unroll
             for (int n = 0; n < WT; ++n) {
-                const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + 256);
+                const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
                 bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         }
