@@ -171,3 +171,48 @@ def test_f16x3_survives_the_reference_init_at_30_blocks():
     print("reference init, 30 blocks: CPU fp32 vs fp64 %.2e, f16x3 vs fp64 %.2e" % (e_cpu, e_hip))
     assert e_hip < max(TOL, 10.0 * e_cpu)
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+
+
+def test_cfg2_bf16_full_batch():
+    """BASELINE configs[1] as stated: RawCTCNet 128 ch x (10 + input) blocks, L=4096, batch 32, bf16.  Size-independent
+    properties at the full size plus one utterance against the oracle; the bf16 error is the storage format's (8 bits)."""
+    from tests.test_gpu_fullsize import _properties
+    from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+    torch.manual_seed(12)
+    layers = [(128, 128, 2, 2 ** i) for i in range(10)]
+    net = RawCTCNet(128, 3, 5, layers, 128, softmax=False, causal=False).to(DEV)
+    W.set_precision(net, "bf16")
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(32, 1, 4096, generator=g).to(DEV)
+    cot = torch.randn(32, 5, 4098, generator=g).to(DEV)
+    y = _properties(net, x, cot, None, 16, causal_prefix=False, additivity_tol=2e-2)
+    assert tuple(y.shape) == (32, 5, 4098)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        y0 = O.raw_ctcnet(x[7:8].cpu(), sd, layers, 3, 1, False, False, False, impl="aten")
+    err = O.rel_err(y[7:8].cpu(), y0)
+    print("cfg2 bf16 forward error vs oracle: %.2e" % err)
+    assert err < 0.1
+
+
+def test_cfg5_f16_full_depth_and_length():
+    """BASELINE configs[4]'s shape on one GPU in its stated dtype: WaveNet 512 ch x 60 blocks x L=48000, batch 2, fp16
+    (conditioned residual path: 60 random-init blocks amplify by ~2^30, beyond fp16 whatever the kernel)."""
+    from tests.test_gpu_fullsize import _layers, _properties, _wavenet
+    c, L, B = 512, 48000, 2
+    layers = _layers(c, 6)
+    net = _wavenet(c, layers, seed=21).to(DEV)
+    W.set_precision(net, "f16")
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, c, L, generator=g).to(DEV)
+    cot = torch.randn(B, c, L, generator=g).to(DEV)
+    _properties(net, x, cot, 8192, 1, causal_prefix=True, additivity_tol=2e-2)
+    # all 60 blocks against the oracle on a shorter utterance
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    xs = x[:1, :, :4000].contiguous()
+    with torch.no_grad():
+        y1 = net(xs).cpu()
+        y0 = O.wavenet(xs.cpu(), sd, layers, False, impl="aten")
+    err = O.rel_err(y1, y0)
+    print("cfg5 f16 forward error vs oracle (60 blocks): %.2e" % err)
+    assert err < 5e-2

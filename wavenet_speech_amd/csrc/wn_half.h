@@ -20,7 +20,7 @@ namespace wn {
 
 enum { HP_F16X3 = 1, HP_F16 = 2, HP_BF16 = 3 };   // = wn_precision values of include/wavenet_amd.h
 constexpr int kHCol = 256;          // time steps per workgroup tile of hgemm_kernel
-constexpr int kHMaxSlab = 8;        // WN_MAX_CHANNELS * 2 / 256
+constexpr int kHMaxSlab = 16;       // WN_MAX_CHANNELS * 2 / 128
 constexpr float kResidualScale = 0.0625f;   // the residual stream is stored as r/16: fp16 then holds |r| up to 1.0e6
 constexpr float kWeightScale = 256.0f;      // weights are packed as 256*w: kaiming-sized weights (~0.05) sit in fp16's normal range
 
@@ -86,7 +86,7 @@ struct HPackSet {
 };
 struct HPackArgs {
     HPackSet set[2];
-    PackTile tile[kHMaxSlab * 8];   // [slab * (ROWS/32) + row tile]: source set and its first row (row0 < 0: zero tile)
+    PackTile tile[kHMaxSlab * 8];   // [slab * (ROWS/32) + row tile] (16 slabs x 4 tiles or 8 x 8): source set and its first row (row0 < 0: zero tile)
     int seg_nks[kMaxSeg];
     long long slab_woff[kHMaxSlab]; // bytes
     int slab_nseg[kHMaxSlab];

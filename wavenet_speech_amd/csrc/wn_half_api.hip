@@ -79,9 +79,14 @@ struct HPlan {
     int slab_nseg[kHMaxSlab] = {0}, slab_row0[kHMaxSlab] = {0}, slab_boff[kHMaxSlab] = {0};
     long long wbytes = 0;
     int bfloats = 0;
-    void init(int out_rows, int planes_) {   // 256-row workgroup tiles for wide outputs, 128-row tiles otherwise
+    // Tile choice (measured at 256 ch x 16 x 16000, f16x3, same run; profiles/r02/half_tuning.txt):
+    //   long_k = false (the block GEMMs, K <= 5 C): 128-row tiles, two workgroups per CU -- their epilogues are HBM-bound
+    //            store bursts (gate writes three tensors) that overlap the other workgroup's K loop: gate 0.510 -> 0.467 ms,
+    //            dz 0.370 -> 0.302, res 0.242 -> 0.229, dx 0.413 -> 0.403
+    //   long_k = true  (skips_sum, K = 30 C): 256-row tiles, one workgroup per CU -- half the weight re-staging: 2.20 vs 2.53 ms
+    void init(int out_rows, int planes_, bool long_k = false) {
         static const int force = getenv("WN_HALF_MT") ? atoi(getenv("WN_HALF_MT")) : 0;   // measurement knob
-        MT = out_rows > 128 ? 4 : 2;
+        MT = (long_k && out_rows > 128) ? 4 : 2;
         if (force == 2 || force == 4) MT = force;
         rows = 64 * MT;
         planes = planes_;
@@ -450,7 +455,7 @@ int check_hskipsum(const wn_skipsum_shape* s, int prec) {
 }
 HPlan plan_hskipsum(const wn_skipsum_shape* s, int prec) {
     HPlan g;
-    g.init(s->skip_rows, hp_planes(prec));
+    g.init(s->skip_rows, hp_planes(prec), true);
     g.nseg = s->nblocks;
     for (int l = 0; l < s->nblocks; ++l) g.seg_nks[l] = cp32(s->channels[l]) / 16;
     for (int r0 = 0; r0 < s->skip_rows; r0 += g.rows) g.add_slab(s->nblocks, r0);
