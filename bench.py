@@ -223,7 +223,7 @@ SYMBOL_OF = {
     "hgemm_kernel<dx>": "hlinear", "hgemm_kernel<skips_sum>": "hlinear", "hwgrad_kernel": "hwgrad",
 }
 SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm_kernel<\d+, \d+, 1,",
-             "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"wgrad_kernel<",
+             "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"(?<![a-z])wgrad_kernel<",
              "hlinear": r"hgemm_kernel<\d+, \d+, \w+, [03]>", "hgate": r"hgemm_kernel<\d+, \d+, \w+, 1>",
              "hdgate": r"hgemm_kernel<\d+, \d+, \w+, 2>",
              "hwgrad": r"hwgrad_kernel<"}

@@ -34,6 +34,51 @@ def test_quantisation_matches_numpy_digitize():
     assert torch.all(mapped[1:] >= mapped[:-1])                    # mu-law is monotone
 
 
+def _check_against_reference_fixture(device):
+    """tests/golden/generator_00.npz: outputs of the reference's own k-mer window, quantize_fn and one_hot_fn"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generator_00.npz"), allow_pickle=False)
+    table = (torch.from_numpy(z["table.means"]).to(device), torch.from_numpy(z["table.stdvs"]).to(device))
+    for case in range(3):
+        pre = "case%d." % case
+        ups, nl = int(z[pre + "upsampling"]), int(z[pre + "num_levels"])
+        bases = torch.from_numpy(z[pre + "bases"]).to(device)
+        kmers = S.kmer_indices(bases, ups)
+        assert np.array_equal(kmers.cpu().numpy(), z[pre + "kmer_seq"]), "k-mer window / trim / upsampling"
+        assert np.array_equal(table[0][kmers].cpu().numpy(), z[pre + "kmer_means"])
+        pico = table[0][kmers] + table[1][kmers] * torch.from_numpy(z[pre + "noise"]).to(device)
+        assert np.allclose(pico.cpu().numpy(), z[pre + "picoamps"], rtol=1e-14, atol=0)
+        q = S.quantize(torch.from_numpy(z[pre + "picoamps"]).to(device), nl)
+        assert np.array_equal(q.cpu().numpy(), z[pre + "quantized"]), "normalise / mu-law / digitize"
+        oh = S.one_hot(q, nl)
+        assert oh.dtype == torch.float32 and np.array_equal(oh.cpu().numpy(), z[pre + "one_hot"])
+
+
+def test_deterministic_stages_match_the_reference_generator():
+    _check_against_reference_fixture("cpu")
+
+
+def test_gaussian_stage_statistics():
+    """the one random stage: per k-mer the samples have the table's mean and standard deviation"""
+    means, stdvs = S.standin_kmer_table()
+    kmers = torch.tensor([5, 700, 1023]).repeat_interleave(20000)
+    x = S.gaussian_picoamps(kmers, (means.double(), stdvs.double()), torch.Generator().manual_seed(3)).view(3, 20000)
+    for i, k in enumerate((5, 700, 1023)):
+        assert abs(float(x[i].mean()) - float(means[k])) < 0.1 and abs(float(x[i].std()) - float(stdvs[k])) < 0.1
+
+
+@pytest.mark.gpu
+def test_generator_on_the_device_matches_the_reference_fixture_and_draws_there():
+    _check_against_reference_fixture("cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    levels, oh, bases = S.gaussian_kmer_signal(2, 300, generator=g, device="cuda:0")
+    assert levels.is_cuda and oh.is_cuda and bases.is_cuda
+    g2 = torch.Generator(device="cuda:0").manual_seed(7)
+    levels2, _, _ = S.gaussian_kmer_signal(2, 300, generator=g2, device="cuda:0")
+    assert torch.equal(levels, levels2)
+    assert int(levels.min()) >= 1 and int(levels.max()) <= 255
+
+
 @pytest.mark.gpu
 def test_config0_wavenet_overfit_script():
     from torch.optim.lr_scheduler import ReduceLROnPlateau
@@ -42,7 +87,7 @@ def test_config0_wavenet_overfit_script():
     dev = "cuda:0"
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
-    _, signal, _ = S.gaussian_kmer_signal(1, 401, num_levels=32, generator=g, device=dev)   # generated on the GPU
+    _, signal, _ = S.gaussian_kmer_signal(1, 401, num_levels=32, generator=g, device=dev)   # generated on the GPU, RNG included
     source, target = signal[:, :, :-1].contiguous(), signal[:, :, 1:].argmax(1)
     net = WaveNet(32, 2, [(32, 32, 2, d) for d in (1, 2, 4, 8, 16)], 32, softmax=False).to(dev)
     opt = torch.optim.Adadelta(net.parameters(), lr=1.0, rho=0.9, weight_decay=1e-4)   # wavenet_overfit_test.py:33-37

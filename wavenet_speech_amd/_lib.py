@@ -91,6 +91,10 @@ SIGNATURES = {
     "wn_hblock_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, POINTER(BlockParams), c_float_p, c_void_p, c_size_t, c_void_p]),
+    "wn_embed_forward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wn_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "wn_embed_backward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
     "wn_nll_partials": (c_size_t, [c_int, c_int]),
     "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     typedef typename BVec<NT>::reg_t breg_t;
     constexpr int COLS = 32 * NT;
     const int lane = threadIdx.x;
-    const int n = lane & 31, h = lane >> 5;
+    const int n0 = lane & 31, h0 = lane >> 5;   // prologue / K-loop copies (the epilogue recomputes them)
 #ifdef WN_STAMPS
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_t1 = 0, st_t2 = 0;
@@ -76,48 +76,21 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     const int ld = a.ld;
 
     // ---- accumulators ---------------------------------------------------------------------------
-    // EPI_ACCUM (the stack's running skips_sum += ...): the destination tile is loaded straight into the accumulators
-    // here, 8 rows per batch and one batch ahead, with the row's bias added on the way in, so the epilogue is the same
-    // plain store as EPI_LINEAR.  (A read-modify-write epilogue cost 45 us of a 112 us wave: 64 dependent
-    // load->add->store rounds; tools/block_stamps.py.)  Every other epilogue starts from the row's bias.
+    // Every epilogue starts from the row's bias.  (EPI_ACCUM, the stack's running skips_sum += ..., used to preload the
+    // destination tile into the accumulators here; hipcc kept the 256 initial values in VGPRs until the first MFMA and
+    // spilled 79-200 registers.  It is a batched read-modify-write epilogue now, see below.)
     f32x16 acc[MT][NT];
-    if constexpr (EPI == EPI_ACCUM) {
-        const GemmDst d0 = a.dst[sl.dst];
-        const float* pre = d0.base + (long)b * d0.cp * ld + a.halo + t0 + NT * n;
-        constexpr int RB = 8, BPT = 16 / RB, NBATCH = MT * BPT;   // 8-row batches, one batch ahead
-        breg_t stage[2][RB];
-        auto fetch = [&](int bi, breg_t (&dst)[RB]) {
-            const int m = bi / BPT, r0 = (bi % BPT) * RB;
+    // bias: an UNCONDITIONAL load through a pointer that is always valid, times 0 or 1 -- `a.bias ? a.bias[i] : 0` made hipcc
+    // branch around every one of the 64 loads (and, in the EPI_ACCUM preload, spill 79 registers across those branches)
+    const float* bias_p = (a.bias ? a.bias : a.wpacked) + sl.boff;
+    const float bias_on = a.bias ? 1.0f : 0.0f;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                int row = sl.row0 + 32 * m + rowof(r0 + i, h);
-                row = row < d0.rows ? row : d0.rows - 1;   // rows past the end are never stored: clamp, don't branch
-                dst[i] = *reinterpret_cast<const breg_t*>(pre + (unsigned)(row * ld));
-            }
-        };
-        fetch(0, stage[0]);
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int bi = 0; bi < NBATCH; ++bi) {
-            if (bi + 1 < NBATCH) fetch(bi + 1, stage[(bi + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int m = bi / BPT, r0 = (bi % BPT) * RB;
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bias_p[32 * m + rowof(r, h0)] * bias_on;
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r0 + i, h)] : 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t][r0 + i] = stage[bi & 1][i][t] + bv;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bv = a.bias ? a.bias[sl.boff + 32 * m + rowof(r, h)] : 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[m][t][r] = bv;
-            }
+            for (int t = 0; t < NT; ++t) acc[m][t][r] = bv;
         }
     }
 
@@ -137,10 +110,9 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     const unsigned a_off = lane * 16u;
     unsigned a_soff = 0;
     const long tilebase = (long)a.halo + t0;       // wave-uniform column of the tile
-    const long colbase = tilebase + NT * n;        // this lane's first column (epilogues)
     unsigned b_off[4];   // rows 4h..4h+3 of each 8-row k-block belong to this half-wave
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b_off[q] = 4u * ((unsigned)(4 * h + q) * (unsigned)ld + (unsigned)(NT * n));
+    for (int q = 0; q < 4; ++q) b_off[q] = 4u * ((unsigned)(4 * h0 + q) * (unsigned)ld + (unsigned)(NT * n0));
     int seg = 0;
     int seg_left = a.seg[0].nkb;
     __amdgpu_buffer_rsrc_t brs = resource(a.seg[0].base + (long)b * a.seg[0].cp * ld);
@@ -240,6 +212,11 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
     } stamp_out{a.stamps ? a.stamps + 8ull * blockIdx.x : nullptr, st_t0, st_r0, st_t1, st_t2, lane};
 #endif
     // ---- epilogue -----------------------------------------------------------------------------
+    // the lane index is recomputed here (v_mbcnt: one wave per workgroup, so lane == threadIdx.x) instead of being kept
+    // alive across the K loop, which owns the whole register file: hipcc otherwise spills it to scratch and reloads it
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int n = lane_e & 31, h = lane_e >> 5;
+    const long colbase = tilebase + NT * n;        // this lane's first column
     const int c0 = t0 + NT * n;  // first of this lane's NT columns
     if (c0 >= a.L) return;
     auto clip = [&](breg_t v) {  // columns >= L stay zero (the layout's zero tail)
@@ -249,27 +226,53 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
         return v;
     };
 
-    if constexpr (EPI == EPI_LINEAR || EPI == EPI_ACCUM) {
+    if constexpr (EPI == EPI_LINEAR) {
         const GemmDst d = a.dst[sl.dst];
-        int he = h;
-        if constexpr (EPI == EPI_ACCUM) {
-            // opaque to the optimiser: otherwise the row indices / store addresses are CSE'd with the preload's and
-            // kept alive (= spilled) across the whole K loop; they are cheaper to recompute.  (Only the lane half is
-            // hidden: hiding the pointer itself loses its address space and turns the stores into flat_store +
-            // vmcnt(0) drains.)
-            asm volatile("" : "+v"(he));
-        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = sl.row0 + 32 * m + rowof(r, he);
+                const int row = sl.row0 + 32 * m + rowof(r, h);
                 if (row < d.rows) {
                     float* p = d.base + ((long)b * d.cp + row) * ld + colbase;
                     breg_t v;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r];
                     *reinterpret_cast<breg_t*>(p) = clip(v);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (EPI == EPI_ACCUM) {
+        // dst += acc: the old values are fetched a whole batch of rows ahead (8 x 16 B per lane in flight) before any is
+        // used -- row-by-row load->add->store chains cost 45 us of a 112 us wave (tools/block_stamps.py)
+        const GemmDst d = a.dst[sl.dst];
+        constexpr int RB = 8, BPT = 16 / RB, NBATCH = MT * BPT;
+        breg_t old[2][RB];
+        float* const tile = d.base + (long)b * d.cp * ld + colbase;
+        auto fetch = [&](int bi, breg_t (&dst)[RB]) {
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                int row = sl.row0 + 32 * m + rowof(r0 + i, h);
+                row = row < d.rows ? row : d.rows - 1;   // rows past the end are never stored: clamp, don't branch
+                dst[i] = *reinterpret_cast<const breg_t*>(tile + (long)row * ld);
+            }
+        };
+        fetch(0, old[0]);
+#pragma unroll
+        for (int bi = 0; bi < NBATCH; ++bi) {
+            if (bi + 1 < NBATCH) fetch(bi + 1, old[(bi + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = bi / BPT, r0 = (bi % BPT) * RB;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int row = sl.row0 + 32 * m + rowof(r0 + i, h);
+                if (row < d.rows) {
+                    breg_t v;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = acc[m][t][r0 + i] + old[bi & 1][i][t];
+                    *reinterpret_cast<breg_t*>(tile + (long)row * ld) = clip(v);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -28,9 +28,11 @@ constexpr int kPitch = 36;   // LDS row pitch in floats (32 + 4: 16-byte aligned
 
 __device__ __forceinline__ int rowof_w(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// RAGGED = some pair's row count is not a multiple of the workgroup tile: only then are out-of-range staging rows
-// replaced by zeros (4 v_cndmask per staged float4; 65 of the ~150 vector instructions of a chunk).
-template <int WT, bool RAGGED>
+// A pair's row count need not be a multiple of the workgroup tile: staging rows past the end re-read row 0 of the
+// operand (always valid memory) and the outputs they produce -- rows / columns >= M / N of the partial tile, and their
+// row sums -- are never read by wgrad_reduce_kernel.  (They used to be replaced by zeros: 4 v_cndmask per staged float4,
+// 65 of the ~150 vector instructions of a chunk and 11 spilled registers in a separate "ragged" instantiation.)
+template <int WT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int ROWS = 2 * WT * 32;   // rows of the A tile and of the B tile held by the workgroup
     constexpr int PASSES = ROWS / 32;   // staging passes: 32 rows x 32 steps per pass (256 threads x float4)
@@ -71,14 +73,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int trow = tid >> 3, tc = tid & 7;
     const int ld = a.ld;
     unsigned offA[PASSES], offB[PASSES];
-    bool okA[PASSES], okB[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
         const int ar = tm * ROWS + q * 32 + trow, br = tn * ROWS + q * 32 + trow;
-        okA[q] = ar < pr.a_cp;
-        okB[q] = br < pr.b_cp;
-        offA[q] = (unsigned)(((okA[q] ? ar : 0) * ld + 4 * tc) * 4);
-        offB[q] = (unsigned)(((okB[q] ? br : 0) * ld + 4 * tc) * 4);
+        offA[q] = (unsigned)(((ar < pr.a_cp ? ar : 0) * ld + 4 * tc) * 4);
+        offB[q] = (unsigned)(((br < pr.b_cp ? br : 0) * ld + 4 * tc) * 4);
     }
     f32x4 ra[PASSES], rb[PASSES];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -113,12 +112,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // registers -> LDS stage st ([row][t], pitch 36), + row sums of A (`real` = 0 for the duplicate chunk that the
     // branch-free tail iteration stages, so that it is not counted twice)
     auto write_a = [&](int st, int q, float real) {
-        const f32x4 v = (!RAGGED || okA[q]) ? ra[q] : zero4;
+        const f32x4 v = ra[q];
         *reinterpret_cast<f32x4*>(&lds[st * STAGE + (q * 32 + trow) * kPitch + 4 * tc]) = v;
         rs[q] += real * v;   // `real` is 0 for the duplicate tail chunk and for workgroups that emit no row sums
     };
     auto write_b = [&](int st, int q) {
-        const f32x4 v = (!RAGGED || okB[q]) ? rb[q] : zero4;
+        const f32x4 v = rb[q];
         *reinterpret_cast<f32x4*>(&lds[st * STAGE + ROWS * kPitch + (q * 32 + trow) * kPitch + 4 * tc]) = v;
     };
 
@@ -294,11 +293,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 hipError_t launch_wgrad(int WT, const WgradArgs& a, hipStream_t st) {
     const unsigned grid = (unsigned)(a.ntile_total * a.nsplit);
     if (grid == 0) return hipSuccess;
-    bool ragged = false;
-    for (int p = 0; p < a.npair; ++p) ragged = ragged || (a.pair[p].a_cp % (64 * WT)) || (a.pair[p].b_cp % (64 * WT));
-#define WN_LAUNCH_WGRAD(W)                                                                              \
-    if (ragged) hipLaunchKernelGGL((wgrad_kernel<W, true>), dim3(grid), dim3(256), 0, st, a);           \
-    else hipLaunchKernelGGL((wgrad_kernel<W, false>), dim3(grid), dim3(256), 0, st, a)
+#define WN_LAUNCH_WGRAD(W) hipLaunchKernelGGL((wgrad_kernel<W>), dim3(grid), dim3(256), 0, st, a)
     switch (WT) {
         case 1: WN_LAUNCH_WGRAD(1); break;
         case 2: WN_LAUNCH_WGRAD(2); break;

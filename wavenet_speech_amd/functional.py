@@ -443,6 +443,56 @@ def sequence_nll(logits, target):
     return _SequenceNLLFn.apply(logits, target)
 
 
+class _EmbedConvFn(torch.autograd.Function):
+    """CausalConv1d(d=1) applied to one_hot(levels) (modules/wavenet.py:54,93 + modules/fns.py:6-15) as a gather of weight
+    columns: the [B, classes, L] one-hot is never built."""
+
+    @staticmethod
+    @_on_device_of_first_tensor
+    def forward(ctx, weight, bias, levels):
+        lib = _lib.load()
+        _require_device(weight, "weight")
+        if levels.dtype != torch.int64 or not levels.is_cuda or levels.dim() != 2:
+            raise RuntimeError("wavenet_speech_amd: levels must be an int64 device tensor [B, L]")
+        Co, classes, k = weight.shape
+        B, L = levels.shape
+        q = levels.contiguous()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        y = torch.empty(B, Co, L, dtype=torch.float32, device=weight.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=weight.device)
+        _lib.check(lib.wn_embed_forward(_p(q), _p(w), _p(b), _p(y), B, L, classes, Co, k, _p(bad), _stream()), "wn_embed_forward")
+        if os.environ.get("WN_NLL_CHECK", "1") != "0":
+            nbad = int(bad.item())
+            if nbad:
+                raise RuntimeError("wavenet_speech_amd: %d thread(s) saw a level outside [0, %d)" % (nbad, classes))
+        ctx.save_for_backward(q)
+        ctx.dims, ctx.has_bias = (B, L, classes, Co, k), bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    @_on_device_of_first_tensor
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        (q,) = ctx.saved_tensors
+        B, L, classes, Co, k = ctx.dims
+        dev = d_y.device
+        dy = d_y.contiguous()
+        dw = torch.empty(Co, classes, k, dtype=torch.float32, device=dev)
+        db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws_bytes = lib.wn_embed_workspace_bytes(B, L, classes, Co, k)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(lib.wn_embed_backward(_p(q), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, B, L, classes, Co, k, _stream()),
+                   "wn_embed_backward")
+        return dw, db, None
+
+
+def embed_conv(levels, weight, bias):
+    """entry_conv1d(one_hot(levels)) without the one-hot: levels [B, L] int64 -> [B, Co, L]"""
+    return _EmbedConvFn.apply(weight, bias, levels)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # measurement hooks
 # ------------------------------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as HF
 from .block import ResidualBlock, StackState, run_stack
 from .conv_ops import CausalConv1d
 from .pointwise import run_sequential
@@ -43,8 +44,20 @@ class WaveNet(nn.Module):
                 p.data.zero_()
         _init_weights_and_zero_bias(self.output_stack.parameters())
 
+    def forward_levels(self, levels):
+        """forward(one_hot(levels)) for quantised input levels [B, L] (int64 in [0, in_dim)): the entry conv becomes a gather
+        of weight columns and the dense one-hot (262 MB at 16 x 256 x 16000) is never built.  The reference builds the
+        one-hot with modules/fns.py:6-15 and multiplies it (modules/wavenet.py:54,93); nn.Module.forward is unchanged."""
+        if self.entry_conv1d.dilation != 1:
+            raise RuntimeError("wavenet_speech_amd: forward_levels needs the reference's dilation-1 entry conv")
+        out = HF.embed_conv(levels, self.entry_conv1d.conv1d.weight, self.entry_conv1d.conv1d.bias)
+        return self._after_entry(out)
+
     def forward(self, signal):
         out = self.entry_conv1d(signal)
+        return self._after_entry(out)
+
+    def _after_entry(self, out):
         skips_sum = run_stack(out, self.convolutions, self.bottlenecks, self.stack_state)
         output_seq = run_sequential(self.output_stack, skips_sum)
         if not self.softmax:
