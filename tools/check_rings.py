@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Scan the gfx950 assembly of the LDS-DMA ring kernels for a compiler-inserted `s_waitcnt vmcnt(0)` inside the K loop.
+
+hipcc may decide that an LDS read could alias a pending LDS-DMA and drain the whole ring in front of it (it did in
+hwgrad_kernel).  The K loop of every hgemm / hwgrad instantiation must have its counted
+`s_waitcnt vmcnt(N)`, N > 0, right before its s_barrier and no vmcnt(0) between the barrier and the last MFMA.
+usage: hipcc ... -save-temps=obj ; check_rings.py <file.s> [...]"""
+import re, subprocess, sys
+
+bad = 0
+for path in sys.argv[1:]:
+    s = open(path).read()
+    for m in re.finditer(r"^(_ZN2wn\w*(?:hgemm_kernel|hwgrad_kernel)\w*):[^\n]*\n(.*?)\n\.Lfunc_end", s, re.S | re.M):
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        lines = [l.strip() for l in m.group(2).splitlines()]
+        bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+        if not bars:
+            print("BAD  no barrier in", name); bad += 1; continue
+        b = bars[0]
+        counted = [l for l in lines[max(0, b - 4):b] if re.match(r"s_waitcnt vmcnt\(\d+\)", l)]
+        n = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", counted[-1]).group(1)) if counted else -1
+        body = []
+        for l in lines[b + 1:]:
+            if l.startswith("s_barrier") or l.startswith("s_endpgm"):
+                break
+            body.append(l)
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+        loop = body[:mf[-1] + 1] if mf else body
+        drains = [l for l in loop if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
+        ok = n > 0 and not drains and mf
+        bad += 0 if ok else 1
+        print("%-4s %-72s vmcnt(%d) before the barrier, %d MFMAs, %d vmcnt(0) inside the K loop" % ("ok" if ok else "BAD", name[:72], n, len(mf), len(drains)))
+sys.exit(1 if bad else 0)

@@ -177,12 +177,13 @@ struct BlockPlan {
 
 BlockPlan plan_block(const wn_block_shape* s) {
     BlockPlan p;
+    static const int mt2 = getenv("WN_MT2_MASK") ? atoi(getenv("WN_MT2_MASK")) : 0;   // measurement knob: 1 gate, 2 res/skip, 4 dx
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     // FA: [a;g] interleaved by 32-channel tile pairs;  K = k taps of x
     {
         GemmPlan& g = p.fa;
         const int pairs = tiles32(Co);
-        g.MT = pairs >= 2 ? 4 : 2;
+        g.MT = (pairs >= 2 && !(mt2 & 1)) ? 4 : 2;
         g.nseg = k;
         for (int j = 0; j < k; ++j) g.seg_nkb[j] = cp8(Ci) / 8;
         const int ns = cdiv(2 * pairs, g.MT);
@@ -193,6 +194,7 @@ BlockPlan plan_block(const wn_block_shape* s) {
         GemmPlan& g = p.fb;
         const int rt = tiles32(Co), st = tiles32(Ms);
         g.MT = pick_mt(std::max(rt, st));
+        if ((mt2 & 2) && g.MT == 4) g.MT = 2;
         g.nseg = 2;
         g.seg_nkb[0] = cp8(Co) / 8;
         g.seg_nkb[1] = cp8(Ci) / 8;
@@ -220,6 +222,7 @@ BlockPlan plan_block(const wn_block_shape* s) {
         GemmPlan& g = p.kb;
         const int xt = tiles32(Ci);
         g.MT = pick_mt(xt);
+        if ((mt2 & 4) && g.MT == 4) g.MT = 2;
         g.nseg = 2 * k + 1;
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nkb[j] = cp8(Co) / 8;
         for (int i = 0; i < cdiv(xt, g.MT); ++i) g.add_slab(2 * k + 1, i * g.MT * 32, 0);

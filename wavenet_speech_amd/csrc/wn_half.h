@@ -67,6 +67,7 @@ struct HGemmArgs {
     int gate_rows;          // valid channels of the gate epilogues
     int nslab, B, L, ld, halo;
     int tiles_per_row, ncol;
+    int dbg;                // measurement only (WN_HGEMM_DBG): 1 = skip the K loop, 2 = skip the epilogue
 };
 
 // ---- weight packing ------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@
 //  * a ring of D stages (128 KiB), D-1 k-steps of prefetch in flight, ONE raw s_barrier per k-step and a counted
 //    s_waitcnt vmcnt(N) -- never 0 inside the loop.
 //  * the same XCD-aware blockIdx mapping as the fp32 kernel: all row slabs of one time tile run on one XCD.
+#include <cstdlib>
+
 #include "wn_half.h"
 
 namespace wn {
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 
     int nks = 0;
     for (int s = 0; s < sl.nseg; ++s) nks += a.seg[s].nks;
+    if (a.dbg & 1) nks = 1;   // measurement: epilogue (and one k-step) only
 
     // ---- staging state (all wave-uniform scalars) --------------------------------------------------------------
     const char* a_src = a.wpacked + sl.woff;                 // stage ks of this slab: + ks * A_BYTES
@@ -347,6 +350,17 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
         slot = slot + 1 == D ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the surplus stages before the epilogue's own loads/stores
+    if (a.dbg & 2) {          // measurement: K loop only (the accumulators stay live through a store that never happens)
+        float sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sum += acc[m][n][q];
+        if (sum == 1.2345e-30f && a.flag) a.flag[0] = 7;
+        return;
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     // C/D layout of the 32x32 tile: column = lane & 31, rows (q & 3) + 8 (q >> 2) + 4 h: registers 4i..4i+3 are four
@@ -491,6 +505,8 @@ static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStream_t st) {
     if (a_in.nslab <= 0 || a_in.B <= 0 || a_in.L <= 0) return hipSuccess;
     HGemmArgs a = a_in;
+    static const int dbg = getenv("WN_HGEMM_DBG") ? atoi(getenv("WN_HGEMM_DBG")) : 0;
+    a.dbg = dbg;
     a.tiles_per_row = (a.L + kHCol - 1) / kHCol;
     a.ncol = a.B * a.tiles_per_row;
     const unsigned grid = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));
