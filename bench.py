@@ -133,11 +133,18 @@ def visible_gpus():
     return torch.cuda.device_count()   # counts devices without creating a HIP context
 
 
+def share_one_gpu():
+    """TEST HOOK (tests/test_gpu_driver_contract.py): WN_BENCH_SHARE_GPU=1 lets every rank use GPU 0 and replaces RCCL by gloo
+    (RCCL refuses two ranks on one device), so that the launcher, the process group and every collective call site of this
+    file run with world size 2 on a one-GPU box.  The JSON line says so (`ranks.backend`); never set it for a measurement."""
+    return os.environ.get("WN_BENCH_SHARE_GPU") == "1"
+
+
 def self_launch(args):
     """--gpus N > 1 with no launcher around us: become the launcher.  Nothing has touched the GPU yet (the ranks are
     fresh child processes; this process never initialises HIP)."""
     n = visible_gpus()
-    if n < args.gpus:
+    if n < args.gpus and not (share_one_gpu() and n >= 1):
         die(3, "--gpus %d requested but only %d GPU(s) are visible; refusing to run on fewer" % (args.gpus, n))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -288,6 +295,9 @@ def main():
     import torch
     import torch.distributed as dist
     ndev = visible_gpus()
+    backend = "nccl"
+    if share_one_gpu():
+        local_rank, backend = 0, "gloo"
     if ndev <= local_rank or ndev < 1:
         die(3, "rank %d needs GPU %d but %d GPU(s) are visible (the HIP path has no CPU fallback)" % (rank, local_rank, ndev))
     if not torch.cuda.is_available():
@@ -299,7 +309,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             die(2, "RCCL group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
@@ -557,7 +570,7 @@ def main():
                    "input": "levels (embedding gather)" if levels is not None else
                             ("raw signal" if args.model == "rawctcnet" else "dense one-hot")},
         "per_gpu": round(value / world, 3),
-        "ranks": {"rccl_ranks": dist.get_world_size() if distributed else 0,
+        "ranks": {"rccl_ranks": dist.get_world_size() if distributed else 0, "backend": backend if distributed else None,
                   "launcher": "self" if os.environ.get("WN_BENCH_SELF_LAUNCHED") else ("external" if launched else "none"),
                   "ms_per_step_by_rank": per_rank_ms, "grad_allreduce_ms_by_rank": per_rank_ar,
                   "grad_allreduce_payload_mb": round(sync.payload_bytes() / 1e6, 1)},

@@ -48,6 +48,27 @@ def test_bench_under_torch_distributed_run_one_rank():
     _check(lines[0], 1, False)
 
 
+def test_bench_self_launches_two_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the ranks itself.  On this one-GPU box the two ranks share
+    GPU 0 over gloo (WN_BENCH_SHARE_GPU=1, a test hook: RCCL refuses two ranks on one device) -- the launcher, the process group,
+    barrier, flat-gradient all-reduce, MAX over ranks, per-rank gather and the JSON relay all run with world size 2."""
+    env = dict(os.environ, WN_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY + ["--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    r = d["ranks"]
+    assert r["rccl_ranks"] == 2 and r["launcher"] == "self" and r["backend"] == "gloo"
+    assert len(r["ms_per_step_by_rank"]) == 2 and len(r["grad_allreduce_ms_by_rank"]) == 2
+    assert abs(d["value"] - 2 * 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "split_precision" in d and d["split_precision"]["value"] > 0      # the second line also runs under DP
+
+
 def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

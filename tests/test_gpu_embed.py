@@ -46,8 +46,11 @@ def test_forward_levels_matches_one_hot_path_and_oracle(case):
         assert O.rel_err(g_lv[kk].cpu(), sd[kk].grad) < TOL, kk
 
 
-def test_embed_backward_is_deterministic_and_rejects_bad_levels():
+@pytest.mark.parametrize("mode", ["gemm", "gather"])
+def test_embed_backward_is_deterministic_and_rejects_bad_levels(mode, monkeypatch):
+    """both backward forms: the wgrad GEMM on a transient one-hot (default) and the per-class gather kernel (wn_embed_backward)"""
     from wavenet_speech_amd import functional as HF
+    monkeypatch.setenv("WN_EMBED_BACKWARD", mode)
     torch.manual_seed(0)
     w = torch.randn(48, 256, 2, device=DEV, requires_grad=True)
     b = torch.randn(48, device=DEV, requires_grad=True)
@@ -59,6 +62,11 @@ def test_embed_backward_is_deterministic_and_rejects_bad_levels():
         (HF.embed_conv(q, w, b) * cot).sum().backward()
         grads.append((w.grad.clone(), b.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # against the dense one-hot conv
+    x = torch.zeros(3, 256, 2000, device=DEV).scatter_(1, q.unsqueeze(1), 1.0)
+    w.grad = b.grad = None
+    (HF.dilated_conv(x, w, b, 1, True) * cot).sum().backward()
+    assert O.rel_err(grads[0][0].cpu(), w.grad.cpu()) < 2e-5 and O.rel_err(grads[0][1].cpu(), b.grad.cpu()) < 2e-5
     # classes never seen get an exactly zero gradient column
     q2 = q.clamp(max=99)
     w.grad = None
