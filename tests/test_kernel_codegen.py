@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 def _asm(src, tmp_path):
     out = str(tmp_path / (src + ".s"))
-    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(CSRC, src),
+    r = subprocess.run([HIPCC, "-O3", "-std=c++20", "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(CSRC, src),
                         "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return out

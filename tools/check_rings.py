@@ -16,18 +16,20 @@ for path in sys.argv[1:]:
         bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
         if not bars:
             print("BAD  no barrier in", name); bad += 1; continue
-        b = bars[0]
-        counted = [l for l in lines[max(0, b - 4):b] if re.match(r"s_waitcnt vmcnt\(\d+\)", l)]
-        n = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", counted[-1]).group(1)) if counted else -1
-        body = []
-        for l in lines[b + 1:]:
-            if l.startswith("s_barrier") or l.startswith("s_endpgm"):
-                break
-            body.append(l)
-        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
-        loop = body[:mf[-1] + 1] if mf else body
-        drains = [l for l in loop if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
-        ok = n > 0 and not drains and mf
+        # K-loop segments = the code between a barrier and the next one (or the end) that contains MFMAs
+        segs = []
+        for bi, b in enumerate(bars):
+            e = bars[bi + 1] if bi + 1 < len(bars) else len(lines)
+            body = lines[b + 1:e]
+            mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+            if not mf:
+                continue
+            counted = [l for l in lines[max(0, b - 4):b] if re.match(r"s_waitcnt vmcnt\(\d+\)", l)]
+            n = int(re.match(r"s_waitcnt vmcnt\((\d+)\)", counted[-1]).group(1)) if counted else -1
+            drains = [l for l in body[:mf[-1] + 1] if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
+            segs.append((n, len(mf), len(drains)))
+        ok = bool(segs) and all(n > 0 and d == 0 for n, _, d in segs)
         bad += 0 if ok else 1
+        n, mf, drains = (segs[0][0], [0] * sum(x[1] for x in segs), [0] * sum(x[2] for x in segs)) if segs else (-1, [], [])
         print("%-4s %-72s vmcnt(%d) before the barrier, %d MFMAs, %d vmcnt(0) inside the K loop" % ("ok" if ok else "BAD", name[:72], n, len(mf), len(drains)))
 sys.exit(1 if bad else 0)

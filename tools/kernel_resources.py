@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "wavenet_speech_amd", "csrc")
 files = sys.argv[1:] or ["wn_gemm.hip", "wn_wgrad.hip", "wn_pack.hip"]
 for f in files:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, f),
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-c", os.path.join(src, f),
                           "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     cur = None
     for line in out.splitlines():

@@ -20,6 +20,8 @@
 //    s_waitcnt vmcnt(N) -- never 0 inside the loop.
 //  * the same XCD-aware blockIdx mapping as the fp32 kernel: all row slabs of one time tile run on one XCD.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "wn_half.h"
 
@@ -32,8 +34,16 @@ typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#define WN_GLDS(gp, lp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), \
-                                                         (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+// LDS-DMA from inline asm (M0 = LDS destination base, saved / set / restored inside the statement), counted by hand with the
+// loop's `s_waitcnt vmcnt(N)`: hipcc then knows of no pending LDS write and cannot decide to drain the ring in front of an LDS
+// read (it did exactly that in hwgrad_kernel with the builtin; wn_half_wgrad.hip).
+__device__ __forceinline__ void glds16(const char* gsrc, const char* lds_dst) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#define WN_GLDS(gp, lp) glds16((gp), (lp))
 
 // ---------------------------------------------------------------------------------------------------------------
 // value <-> storage helpers
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     constexpr int A_PW = A_BYTES / 4096, B_PW = B_BYTES / 4096;       // 1 KiB pieces per wave per stage
     constexpr int PW = A_PW + B_PW;
     constexpr int INFLIGHT = (D - 2) * PW;                            // pieces allowed to be outstanding at the wait
+    constexpr int NPAIR = MT * 4;                                     // accumulator tiles per wave
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
     typedef typename HT<BF>::v8 V8;
@@ -274,18 +285,18 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     const char* b_src = a.seg[0].base + (long long)b * a.seg[0].ustride + (unit0 + a.seg[0].off) * 16;
     const unsigned lane16 = lane * 16u;
 
-    auto issue = [&](int slot) {
+    // PW pieces per wave and stage: A_PW of the weight tile, then B_PW of the activation tile (plane, k-group)
+    auto issue_piece = [&](int slot, auto pic) {
+        constexpr int PI = decltype(pic)::value;
         char* stage = lds + slot * STAGE;
-        const char* ap = a_src + (long long)is_ks * A_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < A_PW; ++i) WN_GLDS(ap + i * 4096 + lane16, stage + wave * 1024 + i * 4096);
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg)
-                WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + lane16,
-                        stage + A_BYTES + ((p * 2 + kg) * kHCol + 64 * wave) * 16);
-        // advance; past the last k-step the state stops and the surplus issues re-stage the last step (never read)
+        if constexpr (PI < A_PW) {
+            WN_GLDS(a_src + (long long)is_ks * A_BYTES + wave * 1024 + PI * 4096 + lane16, stage + wave * 1024 + PI * 4096);
+        } else {
+            constexpr int p = (PI - A_PW) / 2, kg = (PI - A_PW) % 2;
+            WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + lane16, stage + A_BYTES + ((p * 2 + kg) * kHCol + 64 * wave) * 16);
+        }
+    };
+    auto issue_advance = [&]() {   // past the last k-step the state stops and the surplus issues re-stage the last step (never read)
         if (is_ks + 1 < nks) {
             ++is_ks;
             b_src += 2LL * ld * 16;
@@ -297,6 +308,11 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                 b_src = ns.base + (long long)b * ns.ustride + (unit0 + ns.off) * 16;
             }
         }
+    };
+    auto issue = [&](int slot) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(slot, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, PW>{});
+        issue_advance();
     };
 
     // ---- accumulators -----------------------------------------------------------------------------------------------
@@ -319,11 +335,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     for (int ks = 0; ks < nks; ++ks) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // this wave's pieces of stage ks have landed
         __builtin_amdgcn_s_barrier();                                      // ... everyone's have; slot ks-1 is free
-        {
-            int wslot = slot - 1;
-            wslot = wslot < 0 ? D - 1 : wslot;
-            issue(wslot);                                                  // stage ks + D - 1 into the slot just freed
-        }
+        const int wslot = slot == 0 ? D - 1 : slot - 1;                    // stage ks + D - 1 goes into the slot just freed
         const char* st = lds + slot * STAGE;
         V8 af[MT][P], bf[4][P];
 #pragma unroll
@@ -333,10 +345,11 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 #pragma unroll
             for (int n = 0; n < 4; ++n) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
+        // the DMA pieces are issued one at a time between the accumulator tiles (piece p after tile floor(p * NPAIR / PW)),
+        // pinned by sched_barrier: their issue cost hides behind MFMAs instead of delaying the k-step's first one
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / 4, n = idx % 4;
                 if constexpr (BF) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
                 } else {
@@ -346,7 +359,18 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
                     }
                 }
-            }
+                [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                    ([&] {
+                        if constexpr ((Q * NPAIR) / PW == idx) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(wslot, std::integral_constant<int, Q>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, PW>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        issue_advance();
         slot = slot + 1 == D ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the surplus stages before the epilogue's own loads/stores

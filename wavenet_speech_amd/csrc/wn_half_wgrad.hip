@@ -16,6 +16,9 @@
 //    wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no float atomics.
 //  * bias gradients (row sums of A over time) come from the A fragments already in registers: v_dot2c_f32_f16 against
 //    (1, 1) in the MFMAs' shadow, two of the wave's four row tiles per wave column.
+#include <type_traits>
+#include <utility>
+
 #include "wn_half.h"
 
 namespace wn {
@@ -103,26 +106,41 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     // different banks for the transposed reads
     const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
     const long long lane_src = ((long long)gq * a.ld + tq) * 16;
-    // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... of every plane of A, then of B
+    // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... : PW pieces per wave and stage, in the
+    // order (plane, j, A then B).  A stage's pieces are issued ONE AT A TIME between the MFMAs of a k-step (see the loop).
+    constexpr int JP = CH / 32 / 4;                 // pieces per plane and operand that one wave stages
+    static_assert(PW == P * JP * 2, "piece count");
     int is_step = s_begin;
-    auto issue = [&](int slot) {
-        char* stage = lds + slot * STAGE;
+    const char* is_a = nullptr;
+    const char* is_b = nullptr;
+    auto stage_sources = [&]() {                    // wave-uniform source bases of the stage to issue next
         const int sb = is_step / a.steps_per_row;
         const int st = (is_step - sb * a.steps_per_row) * 16;
-        const char* asrc = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16 + lane_src;
-        const char* bsrc = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16 + lane_src;
-#pragma unroll
-        for (int pl = 0; pl < P; ++pl)
-#pragma unroll
-            for (int j = 0; j < CH / 32 / 4; ++j) {
-                const int piece = wave + 4 * j;
-                // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay
-                // inside the tensor by re-reading its last four groups
-                const int ga = min(tm * (CH / 8) + 4 * piece, pr.a_groups - 4), gb = min(tn * (CH / 8) + 4 * piece, pr.b_groups - 4);
-                WN_GLDS(asrc + pl * pr.a_pstride + (long long)ga * a.ld * 16, stage + pl * T_PLANE + piece * 1024);
-                WN_GLDS(bsrc + pl * pr.b_pstride + (long long)gb * a.ld * 16, stage + A_BYTES + pl * T_PLANE + piece * 1024);
-            }
-        if (is_step + 1 < s_end) ++is_step;
+        is_a = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16 + lane_src;
+        is_b = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16 + lane_src;
+    };
+    auto issue_piece = [&](int slot, auto pic) {
+        constexpr int PI = decltype(pic)::value;
+        constexpr int pl = PI / (2 * JP), j = (PI % (2 * JP)) / 2;
+        constexpr bool isB = (PI & 1) != 0;
+        char* stage = lds + slot * STAGE;
+        const int piece = wave + 4 * j;
+        // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay inside the
+        // tensor by re-reading its last four groups
+        if constexpr (!isB) {
+            const int ga = min(tm * (CH / 8) + 4 * piece, pr.a_groups - 4);
+            WN_GLDS(is_a + pl * pr.a_pstride + (long long)ga * a.ld * 16, stage + pl * T_PLANE + piece * 1024);
+        } else {
+            const int gb = min(tn * (CH / 8) + 4 * piece, pr.b_groups - 4);
+            WN_GLDS(is_b + pl * pr.b_pstride + (long long)gb * a.ld * 16, stage + A_BYTES + pl * T_PLANE + piece * 1024);
+        }
+    };
+    auto issue_advance = [&]() { if (is_step + 1 < s_end) ++is_step; };   // past the end the last step is staged again
+    auto issue_stage = [&](int slot) {
+        stage_sources();
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(slot, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, PW>{});
+        issue_advance();
     };
 
     f32x16 acc[WT][WT];
@@ -136,11 +154,6 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
 #pragma unroll
     for (int m = 0; m < WT / 2; ++m) rs[m] = 0.0f;
 
-    if (nks > 0) {
-#pragma unroll
-        for (int s = 0; s < D - 1; ++s) issue(s);
-    }
-
     // transposed-read address of this lane inside a piece: 16-lane group sg -> channels 16 sg.., lane 4q+pp -> step q, channels 4pp..
     const int sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
     const int gr = 2 * sg + (pp >> 1);   // group of this lane's channels inside the 32-channel piece
@@ -148,15 +161,24 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int hi_off = (gr >> 1) ? -64 : 64;   // steps 8h + 4 + q4: the unit index with bit 2 flipped
     const bool do_rs = pr.rowsum != 0;
 
+    if (nks > 0) {
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) issue_stage(s);
+    }
+
+    // ---- K loop ---------------------------------------------------------------------------------------------------
+    // Per k-step: counted wait + barrier, the transposed fragment reads of stage ks, then the MFMAs -- with the DMA pieces of
+    // stage ks + D - 1 issued ONE AT A TIME between the accumulator tiles, pinned by sched_barrier, so that their issue cost
+    // (~60 cycles each among MFMAs) hides in the MFMAs' shadow instead of delaying the first MFMA of the k-step.
+    // (A second variant that also double-buffered the fragments and read stage ks + 1 during the MFMAs of stage ks made
+    // hipcc move fragments into AGPRs and spill 81-124 registers; not kept.)
+    constexpr int NPAIR = WT * WT;
     int slot = 0;
     for (int ks = 0; ks < nks; ++ks) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         __builtin_amdgcn_s_barrier();
-        {
-            int wslot = slot - 1;
-            wslot = wslot < 0 ? D - 1 : wslot;
-            issue(wslot);
-        }
+        const int wslot = slot == 0 ? D - 1 : slot - 1;   // the slot of stage ks - 1 is free now
+        stage_sources();
         const char* sa = lds + slot * STAGE + rd + (wm * WT) * 1024;
         const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WT) * 1024;
         u32x4 af[WT][P], bf[WT][P];
@@ -173,10 +195,9 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
                 bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         }
-#pragma unroll
-        for (int m = 0; m < WT; ++m)
-#pragma unroll
-            for (int n = 0; n < WT; ++n) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / WT, n = idx % WT;
                 if constexpr (BF) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
                 } else {
@@ -186,7 +207,15 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
                     }
                 }
-            }
+                // DMA piece p after accumulator tile p * NPAIR / PW
+                if constexpr ((idx * PW) % NPAIR == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(wslot, std::integral_constant<int, idx * PW / NPAIR>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        issue_advance();
         if (do_rs) {   // row sums of A for two of this wave's row tiles (the other wave column takes the other two)
 #pragma unroll
             for (int mm = 0; mm < WT / 2; ++mm) {
