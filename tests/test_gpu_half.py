@@ -216,3 +216,13 @@ def test_cfg5_f16_full_depth_and_length():
     err = O.rel_err(y1, y0)
     print("cfg5 f16 forward error vs oracle (60 blocks): %.2e" % err)
     assert err < 5e-2
+
+
+def test_f16x3_wide_stack_multi_slab():
+    """512 channels: eight 128-row gate slabs, four-slab block GEMMs, two-tile weight gradients"""
+    c = 512
+    layers = [(c, c, 2, d) for d in (1, 64, 4)]
+    net = _cond_wavenet(c, layers, seed=31)
+    g = torch.Generator().manual_seed(32)
+    x, cot = torch.randn(1, c, 700, generator=g), torch.randn(1, c, 700, generator=g)
+    _run(net, x, cot, layers, "f16x3", TOL)

@@ -37,13 +37,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // LDS-DMA from inline asm (M0 = LDS destination base, saved / set / restored inside the statement), counted by hand with the
 // loop's `s_waitcnt vmcnt(N)`: hipcc then knows of no pending LDS write and cannot decide to drain the ring in front of an LDS
 // read (it did exactly that in hwgrad_kernel with the builtin; wn_half_wgrad.hip).
-__device__ __forceinline__ void glds16(const char* gsrc, const char* lds_dst) {
+// Address form: wave-uniform 64-bit base in an SGPR pair + a 32-bit per-lane byte offset (one VGPR that never changes), so a
+// piece costs no vector address arithmetic and no address registers.
+__device__ __forceinline__ void glds16(const char* ubase, unsigned lane_off, const char* lds_dst) {
     const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(ubase), "s"(dst) : "memory");
 }
-#define WN_GLDS(gp, lp) glds16((gp), (lp))
+#define WN_GLDS(ub, lo, lp) glds16((ub), (lo), (lp))
 
 // ---------------------------------------------------------------------------------------------------------------
 // value <-> storage helpers
@@ -244,12 +246,16 @@ template <int MT, int P, bool BF, int EPI>
 __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemmArgs a) {
     constexpr int ROWS = 64 * MT;
     constexpr int A_PLANE = 2 * ROWS * 16, B_PLANE = 2 * kHCol * 16;
-    constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;
+    // a ring stage holds KPS k-steps: one at f16x3 (48 or 24 MFMAs per wave between barriers), two in the one-plane modes
+    // (a single k-step is only 16 or 8 MFMAs there: the barrier, the counted wait and the fragment-read latency that each
+    // stage pays once would weigh twice as much)
+    constexpr int KPS = P == 1 ? 2 : 1;
+    constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, SUB = A_BYTES + B_BYTES, STAGE = KPS * SUB;
     constexpr int LDS_BUDGET = MT == 4 ? 163840 : 81920;
-    constexpr int D = (LDS_BUDGET / STAGE) > 8 ? 8 : (LDS_BUDGET / STAGE);   // ring depth: 5 (f16x3, MT=4) ... 8
-    constexpr int A_PW = A_BYTES / 4096, B_PW = B_BYTES / 4096;       // 1 KiB pieces per wave per stage
+    constexpr int D = (LDS_BUDGET / STAGE) > 8 ? 8 : (LDS_BUDGET / STAGE);   // ring depth: 5 (MT=4), 3 (MT=2)
+    constexpr int A_PW = A_BYTES / 4096, B_PW = B_BYTES / 4096;       // 1 KiB pieces per wave per k-step
     constexpr int PW = A_PW + B_PW;
-    constexpr int INFLIGHT = (D - 2) * PW;                            // pieces allowed to be outstanding at the wait
+    constexpr int INFLIGHT = (D - 2) * KPS * PW;                      // pieces allowed to be outstanding at the wait
     constexpr int NPAIR = MT * 4;                                     // accumulator tiles per wave
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
@@ -286,14 +292,13 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     const unsigned lane16 = lane * 16u;
 
     // PW pieces per wave and stage: A_PW of the weight tile, then B_PW of the activation tile (plane, k-group)
-    auto issue_piece = [&](int slot, auto pic) {
+    auto issue_piece = [&](char* stage, auto pic) {      // stage = LDS image of the k-step being staged
         constexpr int PI = decltype(pic)::value;
-        char* stage = lds + slot * STAGE;
         if constexpr (PI < A_PW) {
-            WN_GLDS(a_src + (long long)is_ks * A_BYTES + wave * 1024 + PI * 4096 + lane16, stage + wave * 1024 + PI * 4096);
+            WN_GLDS(a_src + (long long)is_ks * A_BYTES + wave * 1024 + PI * 4096, lane16, stage + wave * 1024 + PI * 4096);
         } else {
             constexpr int p = (PI - A_PW) / 2, kg = (PI - A_PW) % 2;
-            WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + lane16, stage + A_BYTES + ((p * 2 + kg) * kHCol + 64 * wave) * 16);
+            WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16, lane16, stage + A_BYTES + ((p * 2 + kg) * kHCol + 64 * wave) * 16);
         }
     };
     auto issue_advance = [&]() {   // past the last k-step the state stops and the surplus issues re-stage the last step (never read)
@@ -310,9 +315,13 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
         }
     };
     auto issue = [&](int slot) {
-        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(slot, std::integral_constant<int, I>{}), ...); }
-        (std::make_integer_sequence<int, PW>{});
-        issue_advance();
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk) {
+            char* stage = lds + slot * STAGE + kk * SUB;
+            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(stage, std::integral_constant<int, I>{}), ...); }
+            (std::make_integer_sequence<int, PW>{});
+            issue_advance();
+        }
     };
 
     // ---- accumulators -----------------------------------------------------------------------------------------------
@@ -329,48 +338,68 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     for (int s = 0; s < D - 1; ++s) issue(s);
 
     const unsigned a_rd = (unsigned)((h * ROWS + wm * 32 * MT + r) * 16);
-    const unsigned b_rd = (unsigned)(A_BYTES + (h * kHCol + wn * 128 + r) * 16);
+    const unsigned b_rd = (unsigned)(A_BYTES + (h * kHCol + wn * 128 + r) * 16);   // inside one k-step's image
 
     int slot = 0;
-    for (int ks = 0; ks < nks; ++ks) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // this wave's pieces of stage ks have landed
-        __builtin_amdgcn_s_barrier();                                      // ... everyone's have; slot ks-1 is free
-        const int wslot = slot == 0 ? D - 1 : slot - 1;                    // stage ks + D - 1 goes into the slot just freed
-        const char* st = lds + slot * STAGE;
-        V8 af[MT][P], bf[4][P];
+    for (int ks = 0; ks < nks; ks += KPS) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // this wave's pieces of this stage have landed
+        __builtin_amdgcn_s_barrier();                                      // ... everyone's have; the previous slot is free
+        const int wslot = slot == 0 ? D - 1 : slot - 1;                    // the stage D - 1 ahead goes into the slot just freed
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
+        for (int kk = 0; kk < KPS; ++kk) {
+            const char* st = lds + slot * STAGE + kk * SUB;
+            char* wst = lds + wslot * STAGE + kk * SUB;
+            {
+                V8 af[MT][P], bf[4][P];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 512);
+                for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
-        }
-        // the DMA pieces are issued one at a time between the accumulator tiles (piece p after tile floor(p * NPAIR / PW)),
-        // pinned by sched_barrier: their issue cost hides behind MFMAs instead of delaying the k-step's first one
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ([&] {
-                constexpr int idx = I, m = idx / 4, n = idx % 4;
-                if constexpr (BF) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
-                } else {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
-                    if constexpr (P == 2) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][1], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
-                    }
+                    for (int m = 0; m < MT; ++m) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 512);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
                 }
-                [&]<int... Q>(std::integer_sequence<int, Q...>) {
-                    ([&] {
-                        if constexpr ((Q * NPAIR) / PW == idx) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            issue_piece(wslot, std::integral_constant<int, Q>{});
-                            __builtin_amdgcn_sched_barrier(0);
+                if (kk > 0) {
+                    // an odd K leaves the last stage's second k-step unused (it re-staged the last step): its weight fragments are
+                    // ANDed to zero instead of branching around the MFMAs -- a branch would make every accumulator a phi and
+                    // hipcc then shuttles them between AGPRs and VGPRs (27 spilled registers)
+                    const unsigned keep = (ks + kk < nks) ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            u32x4 bits = __builtin_bit_cast(u32x4, af[m][p]);
+                            bits &= keep;
+                            af[m][p] = __builtin_bit_cast(V8, bits);
                         }
+                }
+                // the DMA pieces are issued one at a time between the accumulator tiles (piece p after tile floor(p * NPAIR / PW)),
+                // pinned by sched_barrier: their issue cost hides behind MFMAs instead of delaying the k-step's first one
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    ([&] {
+                        constexpr int idx = I, m = idx / 4, n = idx % 4;
+                        if constexpr (BF) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                        } else {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                            if constexpr (P == 2) {
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][0], bf[n][1], acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
+                            }
+                        }
+                        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                            ([&] {
+                                if constexpr ((Q * NPAIR) / PW == idx) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    issue_piece(wst, std::integral_constant<int, Q>{});
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }(), ...);
+                        }(std::make_integer_sequence<int, PW>{});
                     }(), ...);
-                }(std::make_integer_sequence<int, PW>{});
-            }(), ...);
-        }(std::make_integer_sequence<int, NPAIR>{});
-        issue_advance();
+                }(std::make_integer_sequence<int, NPAIR>{});
+            }
+            issue_advance();
+        }
         slot = slot + 1 == D ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the surplus stages before the epilogue's own loads/stores

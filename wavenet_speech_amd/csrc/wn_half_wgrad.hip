@@ -37,13 +37,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // issued and the ring degenerates to synchronous staging (measured: SQ_WAIT_ANY 45 % of the wave cycles, 0.85 ms per launch).
 // Hidden in asm the DMAs are counted by hand: one `s_waitcnt vmcnt(N)` + s_barrier per k-step (see the loop).  M0 (the LDS
 // destination base) is compiler-reserved: it is saved, set and restored inside the one statement.
-__device__ __forceinline__ void glds16(const char* gsrc, const char* lds_dst) {
+// Address form: wave-uniform 64-bit base in an SGPR pair + a 32-bit per-lane byte offset (one VGPR that never changes), so a
+// piece costs no vector address arithmetic and no address registers.
+__device__ __forceinline__ void glds16(const char* ubase, unsigned lane_off, const char* lds_dst) {
     const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(ubase), "s"(dst) : "memory");
 }
-#define WN_GLDS(gp, lp) glds16((gp), (lp))
+#define WN_GLDS(ub, lo, lp) glds16((ub), (lo), (lp))
 
 // 4 time rows x 16 channels of 16-bit elements per 16-lane group, transposed: lane i of the group gets channel i's four
 // steps (the builtin lets hipcc count the read and place its wait; an inline-asm read would need both done by hand)
@@ -68,10 +70,11 @@ template <int WT, int P, bool BF>
 __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     constexpr int CH = 64 * WT;                 // channels of the A tile and of the B tile
     constexpr int T_PLANE = CH * 16 * 2;        // bytes of one operand's plane per k-step (CH channels x 16 steps x 2 B)
-    constexpr int A_BYTES = P * T_PLANE, STAGE = 2 * A_BYTES;
-    constexpr int D = (163840 / STAGE) > 8 ? 8 : (163840 / STAGE);   // 5 stages at f16x3: the whole LDS
-    constexpr int PW = STAGE / 4096;            // 1 KiB pieces per wave per stage
-    constexpr int INFLIGHT = (D - 2) * PW;
+    constexpr int KPS = P == 1 ? 2 : 1;         // k-steps per ring stage: two in the one-plane modes (16 MFMAs per k-step there)
+    constexpr int A_BYTES = P * T_PLANE, SUB = 2 * A_BYTES, STAGE = KPS * SUB;
+    constexpr int D = (163840 / STAGE) > 8 ? 8 : (163840 / STAGE);   // 5 stages: the whole LDS
+    constexpr int PW = SUB / 4096;              // 1 KiB pieces per wave per k-step
+    constexpr int INFLIGHT = (D - 2) * KPS * PW;
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
 
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     // consecutive lanes fetch one whole 128-byte line (8 steps of a group), and the XOR spreads groups g and g + 2 over
     // different banks for the transposed reads
     const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
-    const long long lane_src = ((long long)gq * a.ld + tq) * 16;
+    const unsigned lane_src = (unsigned)((gq * a.ld + tq) * 16);   // < 4 groups x ld x 16 B: fits 32 bits
     // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... : PW pieces per wave and stage, in the
     // order (plane, j, A then B).  A stage's pieces are issued ONE AT A TIME between the MFMAs of a k-step (see the loop).
     constexpr int JP = CH / 32 / 4;                 // pieces per plane and operand that one wave stages
@@ -116,31 +119,34 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     auto stage_sources = [&]() {                    // wave-uniform source bases of the stage to issue next
         const int sb = is_step / a.steps_per_row;
         const int st = (is_step - sb * a.steps_per_row) * 16;
-        is_a = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16 + lane_src;
-        is_b = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16 + lane_src;
+        is_a = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16;
+        is_b = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16;
     };
-    auto issue_piece = [&](int slot, auto pic) {
+    auto issue_piece = [&](char* stage, auto pic) {      // stage = LDS image of the k-step being staged
         constexpr int PI = decltype(pic)::value;
         constexpr int pl = PI / (2 * JP), j = (PI % (2 * JP)) / 2;
         constexpr bool isB = (PI & 1) != 0;
-        char* stage = lds + slot * STAGE;
         const int piece = wave + 4 * j;
         // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay inside the
         // tensor by re-reading its last four groups
         if constexpr (!isB) {
             const int ga = min(tm * (CH / 8) + 4 * piece, pr.a_groups - 4);
-            WN_GLDS(is_a + pl * pr.a_pstride + (long long)ga * a.ld * 16, stage + pl * T_PLANE + piece * 1024);
+            WN_GLDS(is_a + pl * pr.a_pstride + (long long)ga * a.ld * 16, lane_src, stage + pl * T_PLANE + piece * 1024);
         } else {
             const int gb = min(tn * (CH / 8) + 4 * piece, pr.b_groups - 4);
-            WN_GLDS(is_b + pl * pr.b_pstride + (long long)gb * a.ld * 16, stage + A_BYTES + pl * T_PLANE + piece * 1024);
+            WN_GLDS(is_b + pl * pr.b_pstride + (long long)gb * a.ld * 16, lane_src, stage + A_BYTES + pl * T_PLANE + piece * 1024);
         }
     };
     auto issue_advance = [&]() { if (is_step + 1 < s_end) ++is_step; };   // past the end the last step is staged again
     auto issue_stage = [&](int slot) {
-        stage_sources();
-        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(slot, std::integral_constant<int, I>{}), ...); }
-        (std::make_integer_sequence<int, PW>{});
-        issue_advance();
+#pragma unroll
+        for (int kk = 0; kk < KPS; ++kk) {
+            stage_sources();
+            char* stage = lds + slot * STAGE + kk * SUB;
+            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(stage, std::integral_constant<int, I>{}), ...); }
+            (std::make_integer_sequence<int, PW>{});
+            issue_advance();
+        }
     };
 
     f32x16 acc[WT][WT];
@@ -174,60 +180,72 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     // hipcc move fragments into AGPRs and spill 81-124 registers; not kept.)
     constexpr int NPAIR = WT * WT;
     int slot = 0;
-    for (int ks = 0; ks < nks; ++ks) {
+    for (int ks = 0; ks < nks; ks += KPS) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         __builtin_amdgcn_s_barrier();
-        const int wslot = slot == 0 ? D - 1 : slot - 1;   // the slot of stage ks - 1 is free now
-        stage_sources();
-        const char* sa = lds + slot * STAGE + rd + (wm * WT) * 1024;
-        const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WT) * 1024;
-        u32x4 af[WT][P], bf[WT][P];
+        const int wslot = slot == 0 ? D - 1 : slot - 1;   // the previous stage's slot is free now
 #pragma unroll
-        for (int pl = 0; pl < P; ++pl) {
+        for (int kk = 0; kk < KPS; ++kk) {
+            stage_sources();
+            char* wst = lds + wslot * STAGE + kk * SUB;
+            const char* sa = lds + slot * STAGE + kk * SUB + rd + (wm * WT) * 1024;
+            const char* sbb = lds + slot * STAGE + kk * SUB + A_BYTES + rd + (wn * WT) * 1024;
+            u32x4 af[WT][P], bf[WT][P];
 #pragma unroll
-            for (int m = 0; m < WT; ++m) {
-                const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
-                af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
+            for (int pl = 0; pl < P; ++pl) {
 #pragma unroll
-            for (int n = 0; n < WT; ++n) {
-                const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
-                bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-        }
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ([&] {
-                constexpr int idx = I, m = idx / WT, n = idx % WT;
-                if constexpr (BF) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
-                } else {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
-                    if constexpr (P == 2) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
-                    }
+                for (int m = 0; m < WT; ++m) {
+                    const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
+                    af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
-                // DMA piece p after accumulator tile p * NPAIR / PW
-                if constexpr ((idx * PW) % NPAIR == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_piece(wslot, std::integral_constant<int, idx * PW / NPAIR>{});
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < WT; ++n) {
+                    const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
+                    bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
-            }(), ...);
-        }(std::make_integer_sequence<int, NPAIR>{});
-        issue_advance();
-        if (do_rs) {   // row sums of A for two of this wave's row tiles (the other wave column takes the other two)
+            }
+            if (kk > 0) {   // an odd step count leaves the last stage's second k-step unused: zero its A fragments (no branch
+                            // around the MFMAs: that would turn every accumulator into a phi, see hgemm_kernel)
+                const unsigned keep = (ks + kk < nks) ? 0xffffffffu : 0u;
 #pragma unroll
-            for (int mm = 0; mm < WT / 2; ++mm) {
-                const int m = wn * (WT / 2) + mm;   // wave-uniform, but must be a compile-time register index:
+                for (int pl = 0; pl < P; ++pl)
 #pragma unroll
-                for (int mc = 0; mc < WT; ++mc)
-                    if (mc == m) {
-#pragma unroll
-                        for (int pl = 0; pl < P; ++pl)
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) rs[mm] = dot_ones<BF>(af[mc][pl][w], rs[mm]);
+                    for (int m = 0; m < WT; ++m) af[m][pl] &= keep;
+            }
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ([&] {
+                    constexpr int idx = I, m = idx / WT, n = idx % WT;
+                    if constexpr (BF) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    } else {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                        if constexpr (P == 2) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                        }
                     }
+                    // DMA piece p after accumulator tile p * NPAIR / PW
+                    if constexpr ((idx * PW) % NPAIR == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }(), ...);
+            }(std::make_integer_sequence<int, NPAIR>{});
+            issue_advance();
+            if (do_rs) {   // row sums of A for two of this wave's row tiles (the other wave column takes the other two)
+#pragma unroll
+                for (int mm = 0; mm < WT / 2; ++mm) {
+                    const int m = wn * (WT / 2) + mm;   // wave-uniform, but must be a compile-time register index:
+#pragma unroll
+                    for (int mc = 0; mc < WT; ++mc)
+                        if (mc == m) {
+#pragma unroll
+                            for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) rs[mm] = dot_ones<BF>(af[mc][pl][w], rs[mm]);
+                        }
+                }
             }
         }
         slot = slot + 1 == D ? 0 : slot + 1;
