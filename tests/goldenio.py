@@ -34,8 +34,12 @@ class Golden:
             self.meta["layers"] = [tuple(l) for l in self.meta["layers"]]
 
 
+MODEL_PREFIXES = ("conv_", "block_", "wavenet_", "rawctc_", "classifier_")   # generator_*.npz holds data-generator stages, not modules
+
+
 def names(prefix=""):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    found = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in found if n.startswith(MODEL_PREFIXES)]
 
 
 def load(name):
