@@ -19,6 +19,7 @@
 //  * a ring of D stages (128 KiB), D-1 k-steps of prefetch in flight, ONE raw s_barrier per k-step and a counted
 //    s_waitcnt vmcnt(N) -- never 0 inside the loop.
 //  * the same XCD-aware blockIdx mapping as the fp32 kernel: all row slabs of one time tile run on one XCD.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -545,6 +546,16 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 
 template <int MT, int P, bool BF>
 static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
+    static const bool report = getenv("WN_HGEMM_OCCUPANCY") != nullptr;   // measurement: print the occupancy API's answer once
+    if (report) {
+        static bool done = false;
+        if (!done) {
+            done = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_kernel<MT, P, BF, HEPI_GATE>, 256, 0);
+            fprintf(stderr, "[wn] hgemm_kernel<MT=%d, P=%d, BF=%d, GATE>: %d workgroup(s) per CU by the occupancy API\n", MT, P, (int)BF, nb);
+        }
+    }
     switch (epi) {
         case HEPI_STORE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
         case HEPI_GATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_GATE>), dim3(grid), dim3(256), 0, st, a); break;
