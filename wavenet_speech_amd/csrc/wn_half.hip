@@ -351,33 +351,34 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
             const char* st = lds + slot * STAGE + kk * SUB;
             char* wst = lds + wslot * STAGE + kk * SUB;
             {
+                // Fragments are read just in time, two accumulator tiles ahead of their first use (tile (m, n) first needs
+                // af[m] when n == 0 and bf[n] when m == 0), and every step is pinned by sched_barrier: left alone hipcc hoists all
+                // (MT + 4) * P reads to the top and the k-step's first MFMA waits for most of them.  The DMA pieces of the stage
+                // D - 1 ahead are issued one at a time between the tiles (piece p after tile floor(p * NPAIR / PW)), so their
+                // issue cost hides behind MFMAs too.  (K is a whole number of stages: every segment has an even k-step count.)
                 V8 af[MT][P], bf[4][P];
+                auto read_for = [&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t < NPAIR) {
+                        constexpr int m = t / 4, n = t % 4;
+                        if constexpr (n == 0) {
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 512);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
-                }
-                if (kk > 0) {
-                    // an odd K leaves the last stage's second k-step unused (it re-staged the last step): its weight fragments are
-                    // ANDed to zero instead of branching around the MFMAs -- a branch would make every accumulator a phi and
-                    // hipcc then shuttles them between AGPRs and VGPRs (27 spilled registers)
-                    const unsigned keep = (ks + kk < nks) ? 0xffffffffu : 0u;
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            u32x4 bits = __builtin_bit_cast(u32x4, af[m][p]);
-                            bits &= keep;
-                            af[m][p] = __builtin_bit_cast(V8, bits);
+                            for (int p = 0; p < P; ++p) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 512);
                         }
-                }
-                // the DMA pieces are issued one at a time between the accumulator tiles (piece p after tile floor(p * NPAIR / PW)),
-                // pinned by sched_barrier: their issue cost hides behind MFMAs instead of delaying the k-step's first one
+                        if constexpr (m == 0) {
+#pragma unroll
+                            for (int p = 0; p < P; ++p) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 512);
+                        }
+                    }
+                };
+                read_for(std::integral_constant<int, 0>{});
+                read_for(std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
                 [&]<int... I>(std::integer_sequence<int, I...>) {
                     ([&] {
                         constexpr int idx = I, m = idx / 4, n = idx % 4;
+                        read_for(std::integral_constant<int, idx + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
                         if constexpr (BF) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
                         } else {
@@ -387,10 +388,10 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                                 acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
                             }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                         [&]<int... Q>(std::integer_sequence<int, Q...>) {
                             ([&] {
                                 if constexpr ((Q * NPAIR) / PW == idx) {
-                                    __builtin_amdgcn_sched_barrier(0);
                                     issue_piece(wst, std::integral_constant<int, Q>{});
                                     __builtin_amdgcn_sched_barrier(0);
                                 }
@@ -552,18 +553,25 @@ static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream
         if (!done) {
             done = true;
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_kernel<MT, P, BF, HEPI_GATE>, 256, 0);
-            fprintf(stderr, "[wn] hgemm_kernel<MT=%d, P=%d, BF=%d, GATE>: %d workgroup(s) per CU by the occupancy API\n", MT, P, (int)BF, nb);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_kernel<MT, P, BF, HEPI_F32>, 256, 0);
+            fprintf(stderr, "[wn] hgemm_kernel<MT=%d, P=%d, BF=%d>: %d workgroup(s) per CU by the occupancy API\n", MT, P, (int)BF, nb);
         }
     }
-    switch (epi) {
-        case HEPI_STORE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
-        case HEPI_GATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_GATE>), dim3(grid), dim3(256), 0, st, a); break;
-        case HEPI_DGATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_DGATE>), dim3(grid), dim3(256), 0, st, a); break;
-        case HEPI_F32: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a); break;
-        default: return hipErrorInvalidValue;
+    if constexpr (MT == 4) {
+        // 256-row tiles are used by the long-K skips_sum product only (HPlan::init): the other epilogues are not instantiated
+        if (epi != HEPI_F32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    } else {
+        switch (epi) {
+            case HEPI_STORE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_STORE>), dim3(grid), dim3(256), 0, st, a); break;
+            case HEPI_GATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_GATE>), dim3(grid), dim3(256), 0, st, a); break;
+            case HEPI_DGATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_DGATE>), dim3(grid), dim3(256), 0, st, a); break;
+            case HEPI_F32: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
     }
-    return hipGetLastError();
 }
 
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStream_t st) {

@@ -85,9 +85,7 @@ struct HPlan {
     //            dz 0.370 -> 0.302, res 0.242 -> 0.229, dx 0.413 -> 0.403
     //   long_k = true  (skips_sum, K = 30 C): 256-row tiles, one workgroup per CU -- half the weight re-staging: 2.20 vs 2.53 ms
     void init(int out_rows, int planes_, bool long_k = false) {
-        static const int force = getenv("WN_HALF_MT") ? atoi(getenv("WN_HALF_MT")) : 0;   // measurement knob
         MT = (long_k && out_rows > 128) ? 4 : 2;
-        if (force == 2 || force == 4) MT = force;
         rows = 64 * MT;
         planes = planes_;
     }

@@ -190,31 +190,42 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
             char* wst = lds + wslot * STAGE + kk * SUB;
             const char* sa = lds + slot * STAGE + kk * SUB + rd + (wm * WT) * 1024;
             const char* sbb = lds + slot * STAGE + kk * SUB + A_BYTES + rd + (wn * WT) * 1024;
+            // Fragments are read just in time, two accumulator tiles ahead of their first use (tile (m, n) first needs af[m] when
+            // n == 0 and bf[n] when m == 0), every step pinned by sched_barrier: left alone hipcc hoists all reads to the top and
+            // the k-step's first MFMA waits for most of them.  An odd step count leaves the last stage's second k-step unused
+            // (one-plane modes): its A fragments are ANDed to zero -- no branch around the MFMAs, which would turn every
+            // accumulator into a phi (see hgemm_kernel).
             u32x4 af[WT][P], bf[WT][P];
+            const unsigned keep = (kk == 0 || ks + kk < nks) ? 0xffffffffu : 0u;
+            auto read_for = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t < NPAIR) {
+                    constexpr int m = t / WT, n = t % WT;
+                    if constexpr (n == 0) {
 #pragma unroll
-            for (int pl = 0; pl < P; ++pl) {
+                        for (int pl = 0; pl < P; ++pl) {
+                            const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
+                            af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                            if constexpr (KPS > 1) af[m][pl] &= keep;
+                        }
+                    }
+                    if constexpr (m == 0) {
 #pragma unroll
-                for (int m = 0; m < WT; ++m) {
-                    const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
-                    af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        for (int pl = 0; pl < P; ++pl) {
+                            const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
+                            bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                        }
+                    }
                 }
-#pragma unroll
-                for (int n = 0; n < WT; ++n) {
-                    const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
-                    bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                }
-            }
-            if (kk > 0) {   // an odd step count leaves the last stage's second k-step unused: zero its A fragments (no branch
-                            // around the MFMAs: that would turn every accumulator into a phi, see hgemm_kernel)
-                const unsigned keep = (ks + kk < nks) ? 0xffffffffu : 0u;
-#pragma unroll
-                for (int pl = 0; pl < P; ++pl)
-#pragma unroll
-                    for (int m = 0; m < WT; ++m) af[m][pl] &= keep;
-            }
+            };
+            read_for(std::integral_constant<int, 0>{});
+            read_for(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 ([&] {
                     constexpr int idx = I, m = idx / WT, n = idx % WT;
+                    read_for(std::integral_constant<int, idx + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
                     if constexpr (BF) {
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
                     } else {
@@ -224,9 +235,9 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                     // DMA piece p after accumulator tile p * NPAIR / PW
                     if constexpr ((idx * PW) % NPAIR == 0) {
-                        __builtin_amdgcn_sched_barrier(0);
                         issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
