@@ -1,0 +1,260 @@
+// Where do the cycles of the half-precision wgrad loop go?  A stand-alone model of hwgrad_kernel<4, 2, false>'s K loop
+// (wn_half_wgrad.hip) whose ingredients can be switched on one by one:
+//      bit 0  fragments re-read from LDS every k-step with ds_read_b64_tr_b16, just in time (else: read once)
+//      bit 1  s_barrier per k-step
+//      bit 2  the 8 LDS-DMA pieces per wave and k-step, streamed from a buffer far larger than the caches
+//      bit 3  v_mfma_f32_16x16x32_f16 (8 x 8 tiles of 16 x 16 per wave) instead of 32x32x16 (4 x 4 tiles of 32 x 32)
+// Each variant runs many launches back to back on random data (DVFS settles), reports wall time per launch, cycles per
+// k-step from s_memtime and the in-kernel clock from s_memrealtime.  Results are meaningless numbers; only time is read.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 -o /tmp/hwgrad_loop tools/probes/hwgrad_loop.hip && /tmp/hwgrad_loop
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void glds16(const char* ubase, unsigned lane_off, const char* lds_dst) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(ubase), "s"(dst) : "memory");
+}
+__device__ __forceinline__ u32x2 ds_read_tr16(const char* p) {
+    const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+constexpr int STAGE = 32768, D = 5, PW = 8, T_PLANE = 8192, A_BYTES = 16384;
+
+template <int V>
+__global__ __launch_bounds__(256, 1) void loop_kernel(const char* src, float* out, unsigned long long* stamps, int nks, int ld,
+                                                       long long tensor_bytes) {
+    constexpr bool READS = (V & 1) != 0, BAR = (V & 2) != 0, DMA = (V & 4) != 0, S16 = (V & 8) != 0;
+    constexpr int WT = S16 ? 8 : 4;                       // tiles per wave row / column
+    constexpr int NPAIR = WT * WT;
+    constexpr int TB = S16 ? 512 : 1024;                  // LDS bytes of one tile's rows in a plane of a stage
+    __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+    for (int i = tid; i < D * STAGE / 16; i += 256)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[(i + 977 * blockIdx.x) & 0xfffff];
+    __syncthreads();
+
+    const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
+    const unsigned lane_src = (unsigned)((gq * ld + tq) * 16);
+    // the real kernel's geometry: 6 tensors [16 utterances][2 planes][32 groups][ld][16 B], 7 operand pairs, time split over
+    // gridDim / 7 workgroups per pair, 1000 k-steps of 16 time steps per utterance
+    const int pair = blockIdx.x % 7, split = blockIdx.x / 7;
+    const char* ta = src + (long long)(pair & 3) * tensor_bytes;
+    const char* tb = src + (long long)(4 + (pair & 1)) * tensor_bytes;
+    const long long pstride = (long long)32 * ld * 16, ustride = 2 * pstride;
+    int is_step = (int)(16000ll * split / (gridDim.x / 7));
+    auto issue_piece = [&](char* stage, auto pic) {
+        constexpr int PI = decltype(pic)::value;
+        constexpr int pl = PI / 4, j = (PI % 4) / 2;
+        constexpr bool isB = (PI & 1) != 0;
+        const int piece = wave + 4 * j;
+        const int sb = is_step / 1000, st = (is_step - sb * 1000) * 16;
+        const char* s = (isB ? tb : ta) + (long long)sb * ustride + pl * pstride + ((long long)(4 * piece) * ld + 256 + st) * 16;
+        glds16(s, lane_src, stage + (isB ? A_BYTES : 0) + pl * T_PLANE + piece * 1024);
+    };
+
+    typedef std::conditional_t<S16, f32x4, f32x16> acc_t;
+    acc_t acc[WT][WT];
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n)
+#pragma unroll
+            for (int q = 0; q < (S16 ? 4 : 16); ++q) acc[m][n][q] = 0.0f;
+
+    const int sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int gr = 2 * sg + (pp >> 1);
+    const unsigned rd = (unsigned)((32 * h + 8 * gr + (q4 ^ (4 * (gr >> 1)))) * 16 + 8 * (pp & 1));
+    const int hi_off = (gr >> 1) ? -64 : 64;
+
+    u32x4 af[WT][2], bf[WT][2];
+    if (!READS) {
+#pragma unroll
+        for (int m = 0; m < WT; ++m)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u32x2 lo = ds_read_tr16(lds + rd + wm * WT * TB + pl * T_PLANE + m * TB), hi = ds_read_tr16(lds + rd + wm * WT * TB + pl * T_PLANE + m * TB + hi_off);
+                af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                const u32x2 lo2 = ds_read_tr16(lds + A_BYTES + rd + wn * WT * TB + pl * T_PLANE + m * TB), hi2 = ds_read_tr16(lds + A_BYTES + rd + wn * WT * TB + pl * T_PLANE + m * TB + hi_off);
+                bf[m][pl] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+            }
+    }
+    if (DMA && S16) {
+        // 16x16x32: a stage is 32 time steps = two 32 KiB images; two stages fit (D = 2), so the whole next stage is issued
+        // in the first half of the current k-step and must land within the second half
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(lds + s * STAGE, std::integral_constant<int, I>{}), ...); }
+            (std::make_integer_sequence<int, PW>{});
+            if (is_step < 15999) ++is_step;
+        }
+    } else if (DMA) {
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(lds + s * STAGE, std::integral_constant<int, I>{}), ...); }
+            (std::make_integer_sequence<int, PW>{});
+            if (is_step < 15999) ++is_step;   // never past the last utterance
+        }
+    }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    int slot = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        if (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S16 ? 0 : (D - 2) * PW) : "memory");
+        if (BAR) __builtin_amdgcn_s_barrier();
+        const int wslot = S16 ? (slot ^ 2) : (slot == 0 ? D - 1 : slot - 1);   // S16: slots {0,1} and {2,3} are the two stages
+        char* wst = lds + wslot * STAGE;
+        const char* sa = lds + slot * STAGE + rd + (wm * WT) * TB;
+        const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WT) * TB;
+        auto read_for = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (READS && t < NPAIR) {
+                constexpr int m = t / WT, n = t % WT;
+                if constexpr (n == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * TB), hi = ds_read_tr16(sa + pl * T_PLANE + m * TB + hi_off);
+                        af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+                if constexpr (m == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * TB), hi = ds_read_tr16(sbb + pl * T_PLANE + n * TB + hi_off);
+                        bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+            }
+        };
+        read_for(std::integral_constant<int, 0>{});
+        read_for(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / WT, n = idx % WT;
+                read_for(std::integral_constant<int, idx + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (S16) {
+                    // a 16x16x32 MFMA spans two 16-step stages in the real layout; here only its cost matters
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                } else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DMA && !S16 && (idx * PW) % NPAIR == 0) {
+                    issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (DMA && S16 && idx % 2 == 0 && idx / 2 < 2 * PW) {   // 16 pieces after tiles 0, 2, ..., 30 of 64
+                    constexpr int pc = idx / 2;
+                    if constexpr (pc == PW) { if (is_step < 15999) ++is_step; }
+                    issue_piece(wst + (pc / PW) * STAGE, std::integral_constant<int, pc % PW>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        if (DMA && is_step < 15999) ++is_step;
+        if (S16) slot ^= 2; else slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.0f;
+#pragma unroll
+    for (int m = 0; m < WT; ++m)
+#pragma unroll
+        for (int n = 0; n < WT; ++n)
+#pragma unroll
+            for (int q = 0; q < (S16 ? 4 : 16); ++q) s += acc[m][n][q];
+    out[(long long)blockIdx.x * 256 + tid] = s;
+    if (lane == 0) {
+        unsigned long long* st = stamps + ((long long)blockIdx.x * 4 + wave) * 4;
+        st[0] = t0; st[1] = t1; st[2] = r0; st[3] = r1;
+    }
+}
+
+__global__ void fill_kernel(unsigned* p, long long n, unsigned seed) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        // two fp16 values of full-range mantissa and sign, exponents 2^-4 .. 2^-1 (a gradient-like spread, never inf/nan)
+        const unsigned lo = (x & 0x83ff) | ((11 + ((x >> 10) & 3)) << 10), hi = ((x >> 16) & 0x83ff) | ((11 + ((x >> 26) & 3)) << 10);
+        p[i] = lo | (hi << 16);
+    }
+}
+
+template <int V>
+void run(const char* name, const char* src, float* out, unsigned long long* stamps, int grid, int nks, int ld, long long tensor_bytes,
+         int launches) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < launches / 2; ++i) hipLaunchKernelGGL((loop_kernel<V>), dim3(grid), dim3(256), 0, 0, src, out, stamps, nks, ld, tensor_bytes);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL((loop_kernel<V>), dim3(grid), dim3(256), 0, 0, src, out, stamps, nks, ld, tensor_bytes);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> s((size_t)grid * 16);
+    CK(hipMemcpy(s.data(), stamps, s.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> cyc, clk;
+    for (int w = 0; w < grid * 4; ++w) {
+        const double c = (double)(s[w * 4 + 1] - s[w * 4 + 0]), ns = (double)(s[w * 4 + 3] - s[w * 4 + 2]) * 10.0;
+        cyc.push_back(c / nks);
+        clk.push_back(c / ns);
+    }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    const double per = ms / launches;
+    const double flops = 2.0 * 256 * 256 * 16 * 3 * (double)nks * grid * ((V & 8) ? 2.0 : 1.0);
+    printf("%-46s %7.3f ms/launch  %7.1f cyc/k-step (ideal %d)  clock %.2f GHz  %7.0f TFLOP/s (MFMA-counted)\n", name, per,
+           cyc[cyc.size() / 2] / ((V & 8) ? 2.0 : 1.0), 1536, clk[clk.size() / 2], flops / (per * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const int grid = argc > 1 ? atoi(argv[1]) : 504, nks = argc > 2 ? atoi(argv[2]) : 222, launches = argc > 3 ? atoi(argv[3]) : 300;
+    const int ld = 16512;
+    const long long tensor_bytes = 16ll * 2 * 32 * ld * 16;
+    char* src; float* out; unsigned long long* stamps;
+    const long long alloc = 6 * tensor_bytes;
+    if (grid % 7 || 16000 / (grid / 7) < nks) { printf("grid must be a multiple of 7 and nks <= 16000 / (grid / 7)\n"); return 1; }
+    CK(hipMalloc(&src, alloc)); CK(hipMalloc(&out, (size_t)grid * 1024)); CK(hipMalloc(&stamps, (size_t)grid * 128));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (unsigned*)src, alloc / 4, 12345u);
+    CK(hipDeviceSynchronize());
+    printf("grid %d, %d k-steps per workgroup, %d timed launches per variant; source buffer %.2f GB\n", grid, nks, launches, alloc / 1e9);
+    run<0>("MFMA only (32x32x16), operands in registers", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<1>("+ transposed LDS reads", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<3>("+ reads + barrier", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<7>("+ reads + barrier + DMA (the real loop)", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<5>("+ reads + DMA, no barrier (racy)", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<8>("MFMA only (16x16x32)", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<9>("16x16x32 + transposed LDS reads", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<11>("16x16x32 + reads + barrier", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    run<15>("16x16x32 + reads + barrier + DMA, two 64 KiB stages", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    return 0;
+}

@@ -334,6 +334,24 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
 
+    // ---- biases of this wave's rows, fetched before the K loop (128-row tiles) -------------------------------------------
+    // A bias load inside the epilogue sits between stores: vmcnt counts loads and stores together and in order, so waiting
+    // for it drains every store issued before it -- with one small load per row group the epilogue became a chain of
+    // store round trips (8 to 32 full drains per tile).  Fetched here the values cost 32 registers and no wait at all.
+    constexpr bool PRE = (MT == 2) && (EPI != HEPI_DGATE);
+    f32x4 bvec[PRE ? MT : 1][4];
+    if constexpr (PRE) {
+        const float* bias_p = (a.bias ? a.bias + sl.boff : reinterpret_cast<const float*>(a.wpacked + sl.woff)) + wm * 32 * MT + 4 * h;
+        const bool has_bias = a.bias != nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bias_p + 32 * m + 8 * i);   // rows 32 m + 8 i + 4 h + (0..3)
+                bvec[m][i] = has_bias ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+    }
+
     // ---- prologue: D-1 stages in flight -------------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) issue(s);
@@ -423,6 +441,131 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     const float osc = a.oscale;
     unsigned ovf = 0;
     const int rowbase = wm * 32 * MT;                      // first row of this wave inside the slab
+    // FAST PATH: a tile that lies wholly inside the tensor (all 256 columns < L, every row group a real channel group) runs
+    // straight-line code -- no branch, no load between the stores (the dgate epilogue: loads one row group AHEAD of the
+    // stores) -- so hipcc's waits are exact counts and the stores leave back to back.  Every conditional in the general path
+    // below is a control-flow join at which hipcc falls back to `s_waitcnt vmcnt(0)` = a full drain of the stores before it.
+    const bool full_cols = t0 + kHCol <= a.L;
+    if constexpr (PRE && EPI == HEPI_STORE) {
+        const HDst d = a.dst[sl.dst];
+        if (full_cols && sl.row0 + ROWS <= d.cp) {
+            char* dbase = d.base + (long long)b * d.ustride + ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    char* prow = dbase + (long long)((sl.row0 + rowbase + 32 * m + 8 * i) >> 3) * ld * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[m][n][4 * i + q] * osc + bvec[m][i][q];
+                        store4<P, BF>(prow + n * 512, d.pstride, v, ovf);
+                    }
+                }
+            if constexpr (!BF) {
+                if (ovf && a.flag) atomicOr(a.flag, 1u);
+            }
+            return;
+        }
+    } else if constexpr (PRE && EPI == HEPI_GATE) {
+        if (full_cols && sl.row0 + ROWS / 2 <= a.gate_rows) {
+            const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+            char* zb = a.z.base + (long long)b * a.z.ustride + col;
+            const bool keep = a.ta.base != nullptr;            // training: tanh and sigmoid are kept for the backward pass
+            char* tb = keep ? a.ta.base + (long long)b * a.ta.ustride + col : zb;
+            char* sb = keep ? a.sg.base + (long long)b * a.sg.ustride + col : zb;
+#pragma unroll
+            for (int j = 0; j < MT / 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long long o = (long long)((sl.row0 + wm * 16 * MT + 32 * j + 8 * i) >> 3) * ld * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        float vt[4], vs[4], vz[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            vt[q] = h_tanh(acc[2 * j][n][4 * i + q] * osc + bvec[2 * j][i][q]);
+                            vs[q] = h_sigmoid(acc[2 * j + 1][n][4 * i + q] * osc + bvec[2 * j + 1][i][q]);
+                            vz[q] = vt[q] * vs[q];
+                        }
+                        const long long on = o + n * 512;
+                        store4<P, BF>(zb + on, a.z.pstride, vz, ovf);
+                        if (keep) {     // wave-uniform; no load is pending, so the join costs no wait
+                            store4<P, BF>(tb + on, a.ta.pstride, vt, ovf);
+                            store4<P, BF>(sb + on, a.sg.pstride, vs, ovf);
+                        }
+                    }
+                }
+            if constexpr (!BF) {
+                if (ovf && a.flag) atomicOr(a.flag, 1u);
+            }
+            return;
+        }
+    } else if constexpr (MT == 2 && EPI == HEPI_DGATE) {
+        if (full_cols && sl.row0 + ROWS <= a.da.cp) {
+            typedef typename HT<BF>::v4 V4;
+            const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+            const char* tab = a.ta.base + (long long)b * a.ta.ustride + col;
+            const char* sgb = a.sg.base + (long long)b * a.sg.ustride + col;
+            char* dab = a.da.base + (long long)b * a.da.ustride + col;
+            char* dgb = a.dg.base + (long long)b * a.dg.ustride + col;
+            constexpr int NG = MT * 4;                         // row groups of 8 channels per wave
+            V4 rt[2][4][P], rs[2][4][P];                       // raw tanh / sigmoid of a row group, one group ahead
+            auto fetch = [&](int g, V4 (&ft)[4][P], V4 (&fs)[4][P]) {
+                const long long o = (long long)((sl.row0 + rowbase + 8 * g) >> 3) * ld * 16;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 512 + p * a.ta.pstride);
+                        fs[n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 512 + p * a.sg.pstride);
+                    }
+            };
+            fetch(0, rt[0], rs[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) fetch(g + 1, rt[(g + 1) & 1], rs[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int m = g >> 2, i = g & 3;
+                const long long o = (long long)((sl.row0 + rowbase + 8 * g) >> 3) * ld * 16;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    float va[4], vg[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t_ = (float)rt[g & 1][n][0][q], s_ = (float)rs[g & 1][n][0][q];
+                        if constexpr (P == 2) { t_ += (float)rt[g & 1][n][1][q]; s_ += (float)rs[g & 1][n][1][q]; }
+                        const float dz = acc[m][n][4 * i + q] * osc;
+                        va[q] = dz * s_ * (1.0f - t_ * t_);
+                        vg[q] = dz * t_ * s_ * (1.0f - s_);
+                    }
+                    store4<P, BF>(dab + o + n * 512, a.da.pstride, va, ovf);
+                    store4<P, BF>(dgb + o + n * 512, a.dg.pstride, vg, ovf);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!BF) {
+                if (ovf && a.flag) atomicOr(a.flag, 1u);
+            }
+            return;
+        }
+    } else if constexpr (PRE && EPI == HEPI_F32) {
+        if (full_cols && !a.out32_accum && sl.row0 + ROWS <= a.out32_rows) {
+            const float dsc = osc * (a.dyn_inv ? a.dyn_inv[0] : 1.0f);
+            float* pbase = a.out32 + ((long long)b * a.out32_rows + sl.row0 + rowbase + 4 * h) * a.L + t0 + wn * 128 + r;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float* prow = pbase + (long long)(32 * m + (q & 3) + 8 * (q >> 2)) * a.L;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) prow[32 * n] = acc[m][n][q] * dsc + bvec[m][q >> 2][q & 3];
+                }
+            return;
+        }
+    }
+    // ---- general path: ragged tiles (last columns of an utterance, channel counts that end inside the slab) ----------------
     if constexpr (EPI == HEPI_STORE) {
         const HDst d = a.dst[sl.dst];
         char* dbase = d.base + (long long)b * d.ustride + ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;

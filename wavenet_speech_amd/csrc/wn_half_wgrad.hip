@@ -16,6 +16,7 @@
 //    wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no float atomics.
 //  * bias gradients (row sums of A over time) come from the A fragments already in registers: v_dot2c_f32_f16 against
 //    (1, 1) in the MFMAs' shadow, two of the wave's four row tiles per wave column.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int r = lane & 31, h = lane >> 5;
 
     int split, tile;
-    if (a.xcd_map) {
+    if (a.xcd_map & 1) {
         const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
         split = (local / a.ntile_total) * 8 + xcd;
         tile = local % a.ntile_total;
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int tm = tl / pr.nt, tn = tl - tm * pr.nt;
 
     // this split's range of k-steps (16 time steps of one utterance each)
-    const int s_begin = (int)((long long)a.nstep * split / a.nsplit);
-    const int s_end = (int)((long long)a.nstep * (split + 1) / a.nsplit);
+    int s_begin = (int)((long long)a.nstep * split / a.nsplit);
+    int s_end = (int)((long long)a.nstep * (split + 1) / a.nsplit);
     const int nks = s_end - s_begin;
+    if (a.xcd_map & 2) { s_begin = 0; s_end = nks; }   // measurement (WN_HWGRAD_DBG=1): every split re-reads the first range -> operands stay in L2
 
     // ---- staging: each lane's source unit inside a piece (group gq, step tq), see the header comment ----------------
     // unit u = lane of a piece holds (group g, step t) with u = 32 (t >> 3) + 8 g + ((t & 7) ^ 4 (g >> 1)): eight
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                     // DMA piece p after accumulator tile p * NPAIR / PW
                     if constexpr ((idx * PW) % NPAIR == 0) {
-                        issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
+                        if (!(a.xcd_map & 4)) issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }(), ...);
@@ -298,6 +300,12 @@ static hipError_t launch_hw(int prec, const HWgradArgs& a, hipStream_t st) {
 
 hipError_t launch_hwgrad(int prec, const HWgradArgs& a, hipStream_t st) {
     if (a.ntile_total <= 0 || a.nsplit <= 0) return hipSuccess;
+    static const int dbg = getenv("WN_HWGRAD_DBG") ? atoi(getenv("WN_HWGRAD_DBG")) : 0;
+    if (dbg) {
+        HWgradArgs b = a;
+        b.xcd_map |= 2 * dbg;
+        return launch_hw<4>(prec, b, st);
+    }
     return launch_hw<4>(prec, a, st);
 }
 
