@@ -67,7 +67,7 @@ __device__ __forceinline__ V pin(V v) {
 }
 
 // four consecutive channels of one time step -> 8 bytes in plane 0 (and the fp16 remainder in plane 1)
-template <int P, bool BF>
+template <int P, bool BF, bool CHK = true>   // CHK = false: the values cannot exceed fp16's range (tanh, sigmoid and their product)
 __device__ __forceinline__ void store4(char* p, long long pstride, const float (&v)[4], unsigned& ovf) {
     typedef typename HT<BF>::t T;
     typedef typename HT<BF>::v4 V4;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void store4(char* p, long long pstride, const float (
     for (int q = 0; q < 4; ++q) hi[q] = (T)v[q];
     if constexpr (P == 2) hi = pin(hi);
     *reinterpret_cast<V4*>(p) = hi;
-    if constexpr (!BF) {
+    if constexpr (!BF && CHK) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ovf |= (__builtin_fabsf(v[q]) > 65504.0f) ? 1u : 0u;
     }
@@ -470,11 +470,13 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
         }
     } else if constexpr (PRE && EPI == HEPI_GATE) {
         if (full_cols && sl.row0 + ROWS / 2 <= a.gate_rows) {
-            const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
-            char* zb = a.z.base + (long long)b * a.z.ustride + col;
+            long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+            int bq = b;
+            if (a.dbg & 4) { bq = 0; col = ((long long)a.halo + (t0 & 1023) + wn * 128 + r) * 16 + 8 * h; }   // measurement: every tile stores into the first 1024 columns (L2-resident)
+            char* zb = a.z.base + (long long)bq * a.z.ustride + col;
             const bool keep = a.ta.base != nullptr;            // training: tanh and sigmoid are kept for the backward pass
-            char* tb = keep ? a.ta.base + (long long)b * a.ta.ustride + col : zb;
-            char* sb = keep ? a.sg.base + (long long)b * a.sg.ustride + col : zb;
+            char* tb = keep ? a.ta.base + (long long)bq * a.ta.ustride + col : zb;
+            char* sb = keep ? a.sg.base + (long long)bq * a.sg.ustride + col : zb;
 #pragma unroll
             for (int j = 0; j < MT / 2; ++j)
 #pragma unroll
@@ -490,10 +492,10 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                             vz[q] = vt[q] * vs[q];
                         }
                         const long long on = o + n * 512;
-                        store4<P, BF>(zb + on, a.z.pstride, vz, ovf);
+                        store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
                         if (keep) {     // wave-uniform; no load is pending, so the join costs no wait
-                            store4<P, BF>(tb + on, a.ta.pstride, vt, ovf);
-                            store4<P, BF>(sb + on, a.sg.pstride, vs, ovf);
+                            store4<P, BF, false>(tb + on, a.ta.pstride, vt, ovf);
+                            store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
                         }
                     }
                 }
@@ -620,10 +622,10 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                                 vz[q] = vt[q] * vs[q];
                             }
                             const long long on = o + n * 512;
-                            store4<P, BF>(a.z.base + (long long)b * a.z.ustride + on, a.z.pstride, vz, ovf);
+                            store4<P, BF, false>(a.z.base + (long long)b * a.z.ustride + on, a.z.pstride, vz, ovf);
                             if (a.ta.base) {
-                                store4<P, BF>(a.ta.base + (long long)b * a.ta.ustride + on, a.ta.pstride, vt, ovf);
-                                store4<P, BF>(a.sg.base + (long long)b * a.sg.ustride + on, a.sg.pstride, vs, ovf);
+                                store4<P, BF, false>(a.ta.base + (long long)b * a.ta.ustride + on, a.ta.pstride, vt, ovf);
+                                store4<P, BF, false>(a.sg.base + (long long)b * a.sg.ustride + on, a.sg.pstride, vs, ovf);
                             }
                         }
                     }
