@@ -197,6 +197,29 @@ int wn_embed_backward(const long long* levels, const float* dy, float* dweight, 
                       size_t workspace_bytes, int batch, int length, int classes, int out_channels, int kernel_width,
                       wn_stream_t stream);
 
+/* ---- synthetic reads on the device: the reference's on-line generator
+ * utils/gaussian_kmer_model.py:53-104 (gaussian_model_fn :53-73, quantize_fn :79-86, one_hot_fn :89-97), float64 like its
+ * numpy arithmetic.  All pointers are DEVICE pointers.
+ *   wn_synth_bases     nucleotides 1..4 [B][nbases] int64 from a counter-based Philox4x32-10 stream of `seed`
+ *   wn_synth_signal    picoamps[b][t] = means[k] + stdvs[k] * z,  k = 5-mer index of bases[b][p+2 .. p+6], p = t / upsampling
+ *                      (scipy generic_filter's centred window after the [4:-4] trim: n bases give (n - 8) * upsampling
+ *                      samples), z ~ N(0,1) from a second Philox stream of `seed`, or noise[b][t] when `noise` is not NULL
+ *                      (the deterministic stages can then be checked against fixtures).  means / stdvs: 1024 doubles.
+ *                      A base outside 1..4 is counted in *bad_bases (DEVICE int, caller-zeroed, may be NULL).
+ *                      Also leaves per-tile (sum, min, max) partials in `workspace` for the next call.
+ *   wn_synth_quantize  per read (x - mean) / (max - min), mu-law with mu = num_levels, np.digitize against `edges`
+ *                      (num_levels ascending doubles: linspace(-1, 1, num_levels)); levels [B][L] int64 and, unless
+ *                      one_hot is NULL, the dense one-hot [B][num_levels][L] fp32.  The per-read mean is a fixed-order sum:
+ *                      results are bit-reproducible. */
+size_t wn_synth_workspace_bytes(int batch, int length);
+int wn_synth_bases(unsigned long long seed, int batch, int nbases, long long* bases, wn_stream_t stream);
+int wn_synth_signal(const long long* bases, int batch, int nbases, int length, int upsampling, const double* means,
+                    const double* stdvs, unsigned long long seed, const double* noise /* may be NULL */, double* picoamps,
+                    void* workspace, size_t workspace_bytes, int* bad_bases /* may be NULL */, wn_stream_t stream);
+int wn_synth_quantize(const double* picoamps, const void* workspace, size_t workspace_bytes, int batch, int length,
+                      int num_levels, const double* edges, long long* levels, float* one_hot /* may be NULL */,
+                      wn_stream_t stream);
+
 /* ======================================================================================================================
  * Half-precision-MFMA modes of the same path (opt-in; the entry points above stay exact fp32).
  *

@@ -80,6 +80,71 @@ def test_generator_on_the_device_matches_the_reference_fixture_and_draws_there()
 
 
 @pytest.mark.gpu
+def test_hip_generator_matches_the_reference_fixture():
+    """csrc/wn_synth.hip through the C ABI against tests/golden/generator_00.npz (outputs of the reference's own
+    gaussian_model_fn / quantize_fn / one_hot_fn): k-mer window and lookup exactly, the signal with the fixture's noise to
+    1e-14, quantisation and one-hot of the fixture's signal exactly"""
+    import os
+    dev = "cuda:0"
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generator_00.npz"), allow_pickle=False)
+    table = (torch.from_numpy(z["table.means"]).to(dev), torch.from_numpy(z["table.stdvs"]).to(dev))
+    for case in range(3):
+        pre = "case%d." % case
+        ups, nl = int(z[pre + "upsampling"]), int(z[pre + "num_levels"])
+        bases = torch.from_numpy(z[pre + "bases"]).to(dev).long().reshape(1, -1)
+        L = int(z[pre + "kmer_seq"].shape[0])
+        zero = torch.zeros(1, L, dtype=torch.float64, device=dev)
+        _, _, pico0 = S.hip_signal(bases, L, nl, ups, table, noise=zero, want_one_hot=False)
+        assert np.array_equal(pico0.cpu().numpy()[0], z[pre + "kmer_means"]), "k-mer window / trim / upsampling / lookup"
+        noise = torch.from_numpy(z[pre + "noise"]).to(dev).reshape(1, L)
+        _, _, pico = S.hip_signal(bases, L, nl, ups, table, noise=noise, want_one_hot=False)
+        assert np.allclose(pico.cpu().numpy()[0], z[pre + "picoamps"], rtol=1e-14, atol=0)
+        given = torch.from_numpy(z[pre + "picoamps"]).to(dev).reshape(1, L)
+        levels, oh, _ = S.hip_signal(bases, L, nl, ups, table, picoamps=given)
+        assert np.array_equal(levels.cpu().numpy()[0], z[pre + "quantized"]), "normalise / mu-law / digitize"
+        assert oh.dtype == torch.float32 and np.array_equal(oh.cpu().numpy()[0], z[pre + "one_hot"])
+
+
+@pytest.mark.gpu
+def test_hip_generator_random_stages_and_full_size():
+    dev = "cuda:0"
+    # nucleotides: uniform over 1..4, reproducible from the seed
+    b1 = S.hip_bases(8, 50000, 1234, dev)
+    assert torch.equal(b1, S.hip_bases(8, 50000, 1234, dev)) and not torch.equal(b1, S.hip_bases(8, 50000, 1235, dev))
+    assert int(b1.min()) == 1 and int(b1.max()) == 4
+    counts = torch.bincount(b1.flatten(), minlength=5)[1:].double() / b1.numel()
+    assert float((counts - 0.25).abs().max()) < 0.005
+    # Gaussian stage: one k-mer held for the whole read -> the samples have the table's mean and standard deviation,
+    # no skew, normal kurtosis
+    means, stdvs = S.standin_kmer_table(device=dev)
+    for kmer_bases in ((1, 1, 1, 1, 1), (4, 2, 3, 1, 4)):
+        bases = torch.tensor([kmer_bases[0]] * 2 + list(kmer_bases) + [kmer_bases[-1]] * 2, device=dev).repeat(1, 1)
+        k = sum((nt - 1) * w for nt, w in zip(kmer_bases, S.KMER_WEIGHTS))
+        _, _, x = S.hip_signal(bases, 200000, 256, 200000, (means, stdvs), seed=99, want_one_hot=False)
+        x = x[0]
+        zs = (x - float(means[k])) / float(stdvs[k])
+        assert abs(float(zs.mean())) < 0.01 and abs(float(zs.std()) - 1.0) < 0.01
+        assert abs(float((zs ** 3).mean())) < 0.03 and abs(float((zs ** 4).mean()) - 3.0) < 0.08
+        assert abs(float((zs[1:] * zs[:-1]).mean())) < 0.01                 # neighbouring samples are independent
+    # the whole generator at the bench shape: reproducible, in range, one-hot consistent, and the HIP quantiser agrees
+    # with the torch restatement on the same signal (the per-read mean is summed in another order: an exact tie may move)
+    g = torch.Generator(device=dev).manual_seed(7)
+    levels, oh, bases = S.gaussian_kmer_signal(16, 16000, generator=g, device=dev)
+    g2 = torch.Generator(device=dev).manual_seed(7)
+    levels2, _, _ = S.gaussian_kmer_signal(16, 16000, generator=g2, device=dev, want_one_hot=False)
+    assert torch.equal(levels, levels2)
+    assert int(levels.min()) >= 1 and int(levels.max()) <= 255 and oh.shape == (16, 256, 16000)
+    assert torch.equal(oh.argmax(1), levels) and float(oh.sum()) == 16 * 16000
+    _, _, pico = S.hip_signal(bases, 16000, 256, 3, None, seed=5, want_one_hot=False)
+    lv_hip, _, _ = S.hip_signal(bases, 16000, 256, 3, None, picoamps=pico, want_one_hot=False)
+    lv_ref = S.quantize(pico, 256)
+    diff = (lv_hip - lv_ref).abs()
+    assert int(diff.max()) <= 1 and int((diff != 0).sum()) <= 3, (int(diff.max()), int((diff != 0).sum()))
+    kmers = S.kmer_indices(bases, 3)[:, :16000]
+    assert float((pico - means.double()[kmers]).abs().max()) < 6.5 * float(stdvs.max())   # every sample within 6.5 sigma
+
+
+@pytest.mark.gpu
 def test_config0_wavenet_overfit_script():
     from torch.optim.lr_scheduler import ReduceLROnPlateau
     from wavenet_speech_amd import training as T

@@ -6,7 +6,7 @@ fails, a RuntimeError is raised.  Nothing here touches torch.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_amd.so")
@@ -95,6 +95,11 @@ SIGNATURES = {
     "wn_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "wn_embed_backward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
                                   c_int, c_void_p]),
+    "wn_synth_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wn_synth_bases": (c_int, [c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
+    "wn_synth_signal": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p, c_void_p]),
+    "wn_synth_quantize": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wn_nll_partials": (c_size_t, [c_int, c_int]),
     "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),
