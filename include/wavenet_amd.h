@@ -220,6 +220,24 @@ int wn_synth_quantize(const double* picoamps, const void* workspace, size_t work
                       int num_levels, const double* edges, long long* levels, float* one_hot /* may be NULL */,
                       wn_stream_t stream);
 
+/* ---- CTC on the device: replaces the warp-ctc call of Loss.py:49-53 (legacy_code/train.py:46,
+ * pretrain_tnt.py:145,159, which copies the activations to the CPU every step).  warp-ctc semantics: softmax over the
+ * classes inside the loss, one negative log likelihood per utterance (the caller sums them), and the gradient with respect
+ * to the activations comes back with the loss.  Layout is the stack's own: logits / dlogits dense [B][C][T], time fastest --
+ * nothing is permuted.  All pointers are DEVICE pointers.
+ *   labels         [B][max_label_len] int64, utterance b uses the first label_lengths[b]; values in [0, C) and != blank
+ *   label_lengths  [B] int64;  input_lengths [B] int64 or NULL (= every utterance has `length` frames)
+ *   nll            [B] fp32: -log p(labels | logits); +inf when no alignment fits (its gradient rows are zero)
+ *   dlogits        d nll[b] / d logits[b], or NULL for the loss alone
+ * A label outside [0, C), equal to blank, or a length outside its range poisons that utterance (nll = NaN, zero gradient)
+ * and is counted in *bad_labels (DEVICE int, caller-zeroed, may be NULL).  The recursions run in float64.
+ * Limits: C <= 64, max_label_len <= 2047. */
+size_t wn_ctc_workspace_bytes(int batch, int classes, int length, int max_label_len);
+int wn_ctc_loss(const float* logits, const long long* labels, const long long* label_lengths,
+                const long long* input_lengths /* may be NULL */, int batch, int classes, int length, int max_label_len,
+                int blank, float* nll, float* dlogits /* may be NULL */, void* workspace, size_t workspace_bytes,
+                int* bad_labels /* may be NULL */, wn_stream_t stream);
+
 /* ======================================================================================================================
  * Half-precision-MFMA modes of the same path (opt-in; the entry points above stay exact fp32).
  *

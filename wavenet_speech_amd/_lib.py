@@ -100,6 +100,9 @@ SIGNATURES = {
     "wn_synth_signal": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p,
                                 c_void_p, c_size_t, c_void_p, c_void_p]),
     "wn_synth_quantize": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wn_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wn_ctc_loss": (c_int, [c_float_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float_p, c_float_p,
+                            c_void_p, c_size_t, c_void_p, c_void_p]),
     "wn_nll_partials": (c_size_t, [c_int, c_int]),
     "wn_nll_forward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wn_nll_backward": (c_int, [c_float_p, c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_void_p]),

@@ -9,9 +9,9 @@ executed as shipped), on top of the MI355X modules:
     (xe / L + ctc / L').backward(); opt.step()
 
 Differences, all outside the hot path: the per-timestep CE loop is one vectorised cross_entropy call (same value: CE
-averages over the batch at each step and the steps are summed), and CTC stays on the device using
-torch.nn.functional.ctc_loss(log_softmax(.), reduction="sum"), which reproduces the one known answer the reference
-holds for warp-ctc (tests/test_classifier.py:59 -> 2.4628).
+averages over the batch at each step and the steps are summed), and CTC stays on the device: wn_ctc_loss (csrc/wn_ctc.hip)
+reads the [B, labels, T] logits in place and returns loss and gradient, checked against the one known answer the
+reference holds for warp-ctc (tests/test_classifier.py:59 -> 2.4628) and against oracle/ctc_oracle.py.
 """
 import torch
 import torch.nn.functional as F
@@ -27,12 +27,62 @@ def sequence_nll(pred, target):
     return F.cross_entropy(pred, target, reduction="sum") / pred.shape[0]
 
 
-def ctc_total(transcription, labels, label_lengths, blank=0):
+class _CTCFn(torch.autograd.Function):
+    """wn_ctc_loss (csrc/wn_ctc.hip): like warp-ctc the gradient with respect to the activations is produced together with
+    the loss; backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, transcription, labels, label_lengths, input_lengths, blank):
+        import ctypes
+        from . import _lib
+        from .functional import _p, _stream
+        lib = _lib.load()
+        x = transcription.detach().contiguous().float()
+        B, C, T = x.shape
+        dev = x.device
+        labels = labels.to(device=dev, dtype=torch.int64).contiguous()
+        label_lengths = label_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        if labels.dim() != 2 or labels.shape[0] != B or label_lengths.shape != (B,):
+            raise RuntimeError("wavenet_speech_amd: ctc labels must be [B, S] with lengths [B]")
+        in_len = None if input_lengths is None else input_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        lmax = max(int(labels.shape[1]), 1)
+        if labels.shape[1] == 0:
+            labels = torch.zeros(B, 1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            ws_bytes = lib.wn_ctc_workspace_bytes(B, C, T, lmax)
+            if ws_bytes == 0:
+                _lib.check(lib.wn_ctc_loss(None, None, None, None, B, C, T, lmax, blank, None, None, None, 0, None, None),
+                           "wn_ctc_loss")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            nll = torch.empty(B, dtype=torch.float32, device=dev)
+            need_grad = ctx.needs_input_grad[0]
+            dx = torch.empty_like(x) if need_grad else None
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.wn_ctc_loss(_p(x), _p(labels), _p(label_lengths), _p(in_len), B, C, T, lmax, int(blank), _p(nll),
+                                       _p(dx), _p(ws), ws_bytes, _p(bad), _stream()), "wn_ctc_loss")
+            if int(bad.item()):
+                raise RuntimeError("wavenet_speech_amd: ctc labels outside [0, %d), equal to the blank (%d), or lengths out of "
+                                   "range in %d utterance(s)" % (C, blank, int(bad.item())))
+        ctx.dx = dx
+        return nll.sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dx, ctx.dx = ctx.dx, None
+        return (None if dx is None else dx * grad_out), None, None, None, None
+
+
+def ctc_total(transcription, labels, label_lengths, blank=0, input_lengths=None):
     """warp-ctc semantics (Loss.py:49-53): softmax applied internally, negative log likelihoods summed over the batch.
-    transcription: [B, labels, T] logits; labels: [B, S] already offset so that 0 is <BLANK>."""
+    transcription: [B, labels, T] logits; labels: [B, S] already offset so that 0 is <BLANK>.
+    Device tensors go through the HIP kernels (wn_ctc_loss: the logits stay on the GPU and are read in place, where the
+    reference copies them to the CPU for warp-ctc every step, pretrain_tnt.py:159); the torch expression below is the CPU
+    form used by the tests."""
+    if transcription.is_cuda:
+        return _CTCFn.apply(transcription, labels, label_lengths, input_lengths, int(blank))
     logp = F.log_softmax(transcription.permute(2, 0, 1), dim=2)          # (T, B, C)
     T, B = logp.shape[0], logp.shape[1]
-    in_lengths = torch.full((B,), T, dtype=torch.long, device=logp.device)
+    in_lengths = torch.full((B,), T, dtype=torch.long) if input_lengths is None else input_lengths.long()
     return F.ctc_loss(logp, labels, in_lengths, label_lengths, blank=blank, reduction="sum", zero_infinity=False)
 
 
