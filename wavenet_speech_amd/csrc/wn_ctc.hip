@@ -6,15 +6,16 @@
 // logits [B][C][T] with time fastest, so nothing is permuted or copied:
 //
 //   ctc_lse_kernel     lse[b][t] = log sum_c exp(x[b][c][t])                                       (parallel over b, t)
-//   ctc_pass_kernel    log-space alpha (forward) and beta (backward) over the 2 S + 1 blank-extended states, float64:
-//                      one workgroup per (utterance, direction); T sequential steps, one barrier each, the row of the
-//                      previous step in LDS, every row written to HBM.  beta is alpha on reversed time and labels.
-//   ctc_grad_kernel    d nll / d x[b][c][t] = softmax(x)[c] - sum_{s : l'_s = c} exp(alpha_t(s) + beta_t(s) - logp_t(l'_s) + nll)
+//   ctc_pass_kernel    alpha (forward) and beta (backward) over the 2 S + 1 blank-extended states, float64 mantissas with a
+//                      separate integer exponent per state: one workgroup per (utterance, direction); T sequential steps,
+//                      one barrier each, the row of the previous step in LDS, every row written to HBM.  beta is alpha on
+//                      reversed time and labels.
+//   ctc_grad_kernel    d nll / d x[b][c][t] = softmax(x)[c] - sum_{s : l'_s = c} alpha_t(s) beta~_t(s) / sum_s alpha_t(s) beta~_t(s)
 //                      one wave per time step, per-lane private class bins in LDS folded in lane order: deterministic.
 //
-// float64 in the recursions because log-likelihoods of thousands of frames reach magnitudes where fp32 resolves only
-// ~1e-3, which is the relative error the occupancies would inherit.  The passes are latency-bound chains (T steps), not
-// roofline work: measured next to torch's own ctc_loss in profiles/.
+// float64 because a rounding error per step compounds over thousands of frames (torch's fp32 GPU ctc_loss is 2e-2 off in
+// the gradient at 4098 frames, tools/ctc_bench.py).  The passes are latency-bound chains (T steps), not roofline work:
+// measured next to torch's own ctc_loss in profiles/.
 #include "../../include/wavenet_amd.h"
 #include "wn_kernels.h"
 
@@ -24,19 +25,6 @@ constexpr int kCtcThreads = 512;    // states in flight per pass workgroup
 constexpr int kCtcMaxNS = 8;        // states per thread: up to 4096 extended states (2047 labels)
 constexpr int kCtcChunk = 32;       // time steps of log-probabilities staged per refill
 constexpr int kCtcMaxClasses = 64;
-
-#define WN_NEG_INF (-__builtin_huge_val())
-
-__device__ __forceinline__ double lse2(double a, double b) {
-    const double m = fmax(a, b);
-    if (m == WN_NEG_INF) return WN_NEG_INF;
-    return m + log(exp(a - m) + exp(b - m));
-}
-__device__ __forceinline__ double lse3(double a, double b, double c) {
-    const double m = fmax(a, fmax(b, c));
-    if (m == WN_NEG_INF) return WN_NEG_INF;
-    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
-}
 
 __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ x, double* __restrict__ lse, int B, int C, int T) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -56,7 +44,7 @@ struct CtcArgs {
     const long long* label_len;     // [B]
     const long long* input_len;     // [B] or nullptr (= T)
     const double* lse;              // [B][T]
-    double* alpha; double* beta;    // [B][T][Sp]
+    unsigned long long* alpha; unsigned long long* beta;    // [B][T][Sp] {float mantissa, int32 exponent}
     double* nll;                    // [B] (float64 copy used by the gradient kernel)
     float* nll_out;                 // [B]
     float* dx;                      // [B][C][T] or nullptr
@@ -65,6 +53,24 @@ struct CtcArgs {
 };
 
 // dir 0: alpha.  dir 1: beta, computed as alpha on reversed time and reversed labels and stored at the mirrored state.
+//
+// Number format of the recursions: every state value is a pair (m, e), value = m * 2^e, m a float64 in [1, 2) (or m = 0),
+// e a 32-bit integer -- float64 precision with an unlimited exponent range:
+//     sum  = ldexp(m0, e0 - emax) + ldexp(m1, e1 - emax) [+ ldexp(m2, e2 - emax)],  emax = max(e0, e1, e2)
+//     v    = sum * y_t(l'_s);   e' = emax + ilogb(v),  m' = ldexp(v, -ilogb(v))
+// about a dozen hardware instructions (v_ldexp_f64, v_frexp_*) per state and step.  A log-space update costs three exp and
+// one log, which in float64 are software sequences of ~100 instructions each: that version of this kernel spent 2.4 us per
+// time step in them.  Rescaling whole rows by one common factor (Rabiner's scaled forward-backward) is cheaper still but
+// WRONG for long utterances: the states an alignment actually passes through can lie more than e^-709 below the row's
+// largest forward value (measured: 2000 frames x 256 labels on random logits) and vanish from a plain float64 row.
+// Rows go to HBM as {float mantissa, int32 exponent} (8 bytes per state); beta is stored WITHOUT the frame's own emission,
+// so the gradient kernel multiplies alpha_t(s) * beta~_t(s) and never divides by y_t.
+constexpr int kCtcZeroExp = -(1 << 28);                 // exponent of the value 0 (its mantissa is 0: any exponent is right)
+
+__device__ __forceinline__ unsigned long long ctc_pack(double m, int e) {
+    return ((unsigned long long)(unsigned)e << 32) | (unsigned long long)__float_as_uint((float)m);
+}
+
 __global__ __launch_bounds__(kCtcThreads) void ctc_pass_kernel(const CtcArgs a) {
     extern __shared__ double sh[];
     const int b = blockIdx.x, rev = blockIdx.y, tid = threadIdx.x;
@@ -75,9 +81,11 @@ __global__ __launch_bounds__(kCtcThreads) void ctc_pass_kernel(const CtcArgs a) 
     if (bad) { Tb = 0; Lb = 0; }
     const int S = 2 * (int)Lb + 1;
     const long long* lab = a.labels + (long long)b * a.Lmax;
-    double* row0 = sh;                                  // [2][Sp + 2]: two guard entries (-inf) in front of each row
-    double* lp = sh + 2 * (a.Sp + 2);                   // [C][kCtcChunk] log-probabilities of the staged steps
-    int* lbad = reinterpret_cast<int*>(lp + C * kCtcChunk);
+    const int RS = a.Sp + 2;                            // row stride: two guard entries (value 0) in front of each row
+    double* mrow = sh;                                  // [2][RS] mantissas
+    double* yc = sh + 2 * RS;                           // [C][kCtcChunk] softmax probabilities of the staged steps
+    int* erow = reinterpret_cast<int*>(yc + C * kCtcChunk);   // [2][RS] exponents
+    int* lbad = erow + 2 * RS;
     if (tid == 0) *lbad = bad ? 1 : 0;
     __syncthreads();
 
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(kCtcThreads) void ctc_pass_kernel(const CtcArgs a) 
             }
         }
     }
-    for (int i = tid; i < 2 * (a.Sp + 2); i += kCtcThreads) row0[i] = WN_NEG_INF;
+    for (int i = tid; i < 2 * RS; i += kCtcThreads) { mrow[i] = 0.0; erow[i] = kCtcZeroExp; }
     __syncthreads();
     const bool poisoned = *lbad != 0;
     if (poisoned && tid == 0 && rev == 0) {
@@ -115,14 +123,14 @@ __global__ __launch_bounds__(kCtcThreads) void ctc_pass_kernel(const CtcArgs a) 
         }
         return;
     }
-    double* out = (rev ? a.beta : a.alpha) + (long long)b * T * a.Sp;
+    unsigned long long* out = (rev ? a.beta : a.alpha) + (long long)b * T * a.Sp;
     const float* xb = a.x + (long long)b * C * T;
     const double* lseb = a.lse + (long long)b * T;
 
     for (int k = 0; k < (int)Tb; ++k) {
         const int kc = k % kCtcChunk;
         if (kc == 0) {
-            // stage log p of the next kCtcChunk steps: [c][kk] for pass steps k .. k+chunk-1
+            // stage y of the next kCtcChunk steps: [c][kk] for pass steps k .. k+chunk-1
             __syncthreads();                                             // the previous chunk is no longer read
             for (int i = tid; i < C * kCtcChunk; i += kCtcThreads) {
                 const int c = i / kCtcChunk, kk = i - c * kCtcChunk;
@@ -130,38 +138,64 @@ __global__ __launch_bounds__(kCtcThreads) void ctc_pass_kernel(const CtcArgs a) 
                 double v = 0.0;
                 if (ks < (int)Tb) {
                     const int t = rev ? (int)Tb - 1 - ks : ks;
-                    v = (double)xb[(long long)c * T + t] - lseb[t];
+                    v = exp((double)xb[(long long)c * T + t] - lseb[t]);
                 }
-                lp[i] = v;
+                yc[i] = v;
             }
         }
         __syncthreads();                                                 // previous row complete, chunk visible
-        const double* prev = row0 + ((k + 1) & 1) * (a.Sp + 2) + 2;      // row written at step k-1
-        double* cur = row0 + (k & 1) * (a.Sp + 2) + 2;
+        const int po = ((k + 1) & 1) * RS + 2, co = (k & 1) * RS + 2;    // row written at step k-1 / row of this step
         const int t = rev ? (int)Tb - 1 - k : k;
-        double* orow = out + (long long)t * a.Sp;
+        unsigned long long* orow = out + (long long)t * a.Sp;
 #pragma unroll
         for (int i = 0; i < kCtcMaxNS; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < S) {
-                double v;
+                double pre; int pe;
                 if (k == 0) {
-                    v = s < 2 ? 0.0 : WN_NEG_INF;                        // paths start in the first blank or the first label
+                    pre = s < 2 ? 1.0 : 0.0; pe = s < 2 ? 0 : kCtcZeroExp;   // paths start in the first blank or the first label
                 } else {
-                    v = skip[i] ? lse3(prev[s], prev[s - 1], prev[s - 2]) : lse2(prev[s], prev[s - 1]);
+                    const int e0 = erow[po + s], e1 = erow[po + s - 1];
+                    int emax = e0 > e1 ? e0 : e1;
+                    int e2 = kCtcZeroExp;
+                    if (skip[i]) { e2 = erow[po + s - 2]; emax = e2 > emax ? e2 : emax; }
+                    // exponent gaps beyond float64's range contribute 0; clamping keeps the int subtraction away from overflow
+                    double sum = ldexp(mrow[po + s], max(e0 - emax, -2200)) + ldexp(mrow[po + s - 1], max(e1 - emax, -2200));
+                    if (skip[i]) sum += ldexp(mrow[po + s - 2], max(e2 - emax, -2200));
+                    if (sum > 0.0) {
+                        const int ex = ilogb(sum);
+                        pre = ldexp(sum, -ex); pe = emax + ex;
+                    } else {
+                        pre = 0.0; pe = kCtcZeroExp;
+                    }
                 }
-                v += lp[cls[i] * kCtcChunk + kc];
-                cur[s] = v;
-                orow[rev ? S - 1 - s : s] = v;
+                double v = pre * yc[cls[i] * kCtcChunk + kc];
+                int ve = pe;
+                if (v > 0.0) {
+                    const int ex = ilogb(v);
+                    v = ldexp(v, -ex); ve = pe + ex;
+                } else {
+                    v = 0.0; ve = kCtcZeroExp;
+                }
+                mrow[co + s] = v; erow[co + s] = ve;
+                orow[rev ? S - 1 - s : s] = rev ? ctc_pack(pre, pe) : ctc_pack(v, ve);   // beta is stored WITHOUT this frame's emission
             }
         }
     }
     __syncthreads();
     if (tid == 0 && rev == 0) {
-        const double* last = row0 + (((int)Tb - 1) & 1) * (a.Sp + 2) + 2;
-        const double ll = S >= 2 ? lse2(last[S - 1], last[S - 2]) : last[S - 1];   // paths end in the last blank or the last label
-        a.nll[b] = -ll;
-        a.nll_out[b] = (float)(-ll);
+        const int lo = (((int)Tb - 1) & 1) * RS + 2;
+        // paths end in the last blank or the last label
+        double m = mrow[lo + S - 1]; int e = erow[lo + S - 1];
+        if (S >= 2) {
+            const double m2 = mrow[lo + S - 2]; const int e2 = erow[lo + S - 2];
+            const int emax = e > e2 ? e : e2;
+            m = ldexp(m, max(e - emax, -2200)) + ldexp(m2, max(e2 - emax, -2200));
+            e = emax;
+        }
+        const double nll = m > 0.0 ? -(log(m) + (double)e * 0.69314718055994530942) : __builtin_huge_val();
+        a.nll[b] = nll;
+        a.nll_out[b] = (float)nll;
     }
 }
 
@@ -188,29 +222,48 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const CtcArgs a, int step
         if (inside && !compute) {                        // frames past the utterance, infeasible or rejected labellings: no gradient
             for (int c = lane; c < C; c += 64) dxb[(long long)c * T + t] = 0.0f;
         }
-        double lse_t = 0.0;
+        double total = 0.0;
         if (compute) {
             for (int c = 0; c < C; ++c) mine[c] = 0.0;
-            lse_t = a.lse[(long long)b * T + t];
-            const double* ar = a.alpha + ((long long)b * T + t) * a.Sp;
-            const double* br = a.beta + ((long long)b * T + t) * a.Sp;
+            const unsigned long long* ar = a.alpha + ((long long)b * T + t) * a.Sp;
+            const unsigned long long* br = a.beta + ((long long)b * T + t) * a.Sp;
+            // the frame's largest alpha * beta~ exponent (the occupancies are normalised per frame, so any common factor will do)
+            int emax = 2 * kCtcZeroExp;
+            for (int s = lane; s < S; s += 64) {
+                const unsigned long long pa = ar[s], pb = br[s];
+                if ((unsigned)pa != 0u && (unsigned)pb != 0u) {
+                    const int e = (int)(pa >> 32) + (int)(pb >> 32);
+                    emax = e > emax ? e : emax;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(emax, o); emax = v > emax ? v : emax; }
             for (int s = lane; s < S; s += 64) {
                 int c = a.blank;
                 if (s & 1) {
                     const long long l = lab[s >> 1];
                     c = (l >= 0 && l < C) ? (int)l : a.blank;
                 }
-                const double lpv = (double)xb[(long long)c * T + t] - lse_t;
-                mine[c] += exp(ar[s] + br[s] - lpv + nll);   // occupancy of state s at time t (<= 1; the states of a step sum to 1)
+                const unsigned long long pa = ar[s], pb = br[s];
+                const double mm = (double)__uint_as_float((unsigned)pa) * (double)__uint_as_float((unsigned)pb);
+                const int e = (int)(pa >> 32) + (int)(pb >> 32);
+                const double g = mm > 0.0 ? ldexp(mm, max(e - emax, -2200)) : 0.0;   // proportional to the occupancy of state s
+                mine[c] += g;
+                total += g;
             }
+            // the frame's normaliser: the wave's total in a fixed shuffle order
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
         }
         __syncthreads();                                 // private bins complete
         if (compute) {
+            const double lse_t = a.lse[(long long)b * T + t];
+            const double inv = total > 0.0 ? 1.0 / total : 0.0;
             for (int c = lane; c < C; c += 64) {
                 double occ = 0.0;
                 for (int l = 0; l < 64; ++l) occ += bins[((long long)wave * 64 + l) * C + c];   // lane order: deterministic
                 const double y = exp((double)xb[(long long)c * T + t] - lse_t);
-                dxb[(long long)c * T + t] = (float)(y - occ);
+                dxb[(long long)c * T + t] = (float)(y - occ * inv);
             }
         }
         __syncthreads();                                 // bins free for the next step
@@ -256,14 +309,15 @@ int wn_ctc_loss(const float* logits, const long long* labels, const long long* l
     CtcArgs a;
     a.x = logits; a.labels = labels; a.label_len = label_lengths; a.input_len = input_lengths;
     double* w = reinterpret_cast<double*>(workspace);
-    a.lse = w; a.alpha = w + rows; a.beta = a.alpha + rows * Sp; a.nll = a.beta + rows * Sp;
+    a.lse = w; a.alpha = reinterpret_cast<unsigned long long*>(w + rows); a.beta = a.alpha + rows * Sp;
+    a.nll = reinterpret_cast<double*>(a.beta + rows * Sp);
     a.nll_out = nll; a.dx = dlogits; a.bad = bad_labels;
     a.B = batch; a.C = classes; a.T = length; a.Lmax = max_label_len; a.Sp = Sp; a.blank = blank;
     ProfScopeShared prof(KC_CTC, 0.0, st);
     hipLaunchKernelGGL(ctc_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, w, batch, classes, length);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail_shared(e, "ctc_lse");
-    const size_t pass_lds = (size_t)(2 * (Sp + 2) + classes * kCtcChunk) * 8 + 16;
+    const size_t pass_lds = (size_t)(2 * (Sp + 2) + classes * kCtcChunk) * 8 + (size_t)(2 * (Sp + 2)) * 4 + 16;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_pass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pass_lds);
     if (e != hipSuccess) return hip_fail_shared(e, "ctc_pass attribute");
     hipLaunchKernelGGL(ctc_pass_kernel, dim3(batch, dlogits ? 2 : 1), dim3(kCtcThreads), pass_lds, st, a);
