@@ -125,7 +125,7 @@ struct HWgradArgs {
     HWgradPair pair[kMaxPair];
     int npair, ntile_total, nsplit, xcd_map;
     int B, L, ld, halo;
-    int steps_per_row;                  // ceil(L / 16) k-steps per utterance
+    int steps_per_row;                  // ceil(L / 32) stages per utterance
     int nstep;                          // B * steps_per_row
     float* slab; float* rowsum;
     long long slab_floats; int rs_floats;

@@ -552,7 +552,7 @@ int run_hwgrad(const std::vector<HPairSpec>& ps, int prec, int B, int L, int ld,
                size_t workspace_bytes, bool dry, size_t* need, hipStream_t st) {
     HWPlan wp;
     for (const HPairSpec& p : ps) wp.add(p.a_rows, p.b_rows);
-    const int spr = cdiv(L, 16);
+    const int spr = cdiv(L, 32);                      // stages of 32 time steps per utterance (hwgrad_kernel)
     wp.finish(B * spr);
     if (need) *need = wp.bytes();
     if (dry || ps.empty()) return WN_OK;

@@ -3,19 +3,24 @@
 //     out_p[m][n] = sum_{b, t} A_p[b][m][t] * B_p[b][n][t + off_p]          (p = "pair", e.g. dW_tanh_j = sum da[t] x[t+off_j]^T)
 //
 // The contraction index is TIME, but the half-series layout (wn_half.h) keeps 8 CHANNELS of one time step together.
-// v_mfma_f32_32x32x16 wants, per lane, 8 consecutive k (= time steps) of one row (= channel): that transpose is done by
+// v_mfma_f32_16x16x32 wants, per lane, 8 consecutive k (= time steps) of one row (= channel): that transpose is done by
 // the hardware on the way out of LDS with ds_read_b64_tr_b16 (4 time rows x 16 channel columns per 16-lane group,
 // delivered column-major), so staging stays pure LDS-DMA of 16-byte units:
-//  * one stage = one k-step = 16 time steps of the A tile (64*WT channels) and of the B tile (64*WT channels);
-//    a 1 KiB DMA piece = 4 channel groups x 16 time steps = exactly one 32-channel MFMA tile of one k-step.
-//    Inside a piece the unit of (group g, time t) sits at 32*(t>>3) + 8*g + ((t&7) ^ 4*(g>>1)): eight consecutive lanes
-//    of the DMA fetch one whole 128-byte line (8 steps of a group), and the sixteen units one half-wave's transposed read
-//    touches (4 groups x 4 consecutive steps) fall into 16 different 16-byte slots = all 64 banks once.
-//    (The DMA source address is per lane, so the permutation costs nothing.)
-//  * workgroup = 4 waves (2 x 2), each wave a (32*WT)^2 tile of fp32 accumulators; split-K over time into slabs that
-//    wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no float atomics.
+//  * one stage = one MFMA k-step = 32 time steps of the A tile (256 channels) and of the B tile (256 channels);
+//    a 1 KiB DMA piece = 2 channel groups x 32 time steps = exactly one 16-channel MFMA operand tile of the stage.
+//    Inside a piece the unit of (group g, step t = 8 kb + 4 ph + q) sits at 16 (2 (kb >> 1) + ph) + 8 g + 4 (kb & 1) + q:
+//    the sixteen units one half-wave's transposed read touches (2 groups x 2 k-blocks x 4 consecutive steps) fall into 16
+//    different 16-byte slots = all 64 banks once, the second four steps of a k-block are the same address + 256 B, and
+//    four consecutive DMA lanes fetch 64 contiguous bytes.  (The DMA source address is per lane: the permutation is free.)
+//  * the 16x16x32 shape, not 32x32x16: at equal cycles per FLOP the chip holds ~2.2 GHz under it against ~1.75 GHz
+//    (tools/probes/hwgrad_loop.hip) -- these kernels run at the power limit, so that is +15 % in the loop model.
+//    A stage is therefore 64 KiB at f16x3: a two-stage ring, the whole next stage issued during the first half of the
+//    current one; five stages of 32 KiB in the one-plane modes.
+//  * workgroup = 4 waves (2 x 2), each wave a 128 x 128 tile of fp32 accumulators (8 x 8 MFMA tiles, 256 registers);
+//    split-K over time into slabs that wgrad_reduce_kernel (wn_wgrad.hip) sums in a fixed order -- deterministic, no
+//    float atomics.
 //  * bias gradients (row sums of A over time) come from the A fragments already in registers: v_dot2c_f32_f16 against
-//    (1, 1) in the MFMAs' shadow, two of the wave's four row tiles per wave column.
+//    (1, 1) in the MFMAs' shadow, four of the wave's eight row tiles per wave column.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -67,22 +72,22 @@ __device__ __forceinline__ float dot_ones(unsigned packed_pair, float acc) {
     }
 }
 
-template <int WT, int P, bool BF>
+template <int P, bool BF>
 __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
-    constexpr int CH = 64 * WT;                 // channels of the A tile and of the B tile
-    constexpr int T_PLANE = CH * 16 * 2;        // bytes of one operand's plane per k-step (CH channels x 16 steps x 2 B)
-    constexpr int KPS = P == 1 ? 2 : 1;         // k-steps per ring stage: two in the one-plane modes (16 MFMAs per k-step there)
-    constexpr int A_BYTES = P * T_PLANE, SUB = 2 * A_BYTES, STAGE = KPS * SUB;
-    constexpr int D = (163840 / STAGE) > 8 ? 8 : (163840 / STAGE);   // 5 stages: the whole LDS
-    constexpr int PW = SUB / 4096;              // 1 KiB pieces per wave per k-step
-    constexpr int INFLIGHT = (D - 2) * KPS * PW;
+    constexpr int CH = 256;                     // channels of the A tile and of the B tile
+    constexpr int KT = 32;                      // time steps per stage = the contraction depth of one 16x16x32 MFMA
+    constexpr int T_PLANE = CH * KT * 2;        // bytes of one operand's plane per stage (16 KiB)
+    constexpr int A_BYTES = P * T_PLANE, STAGE = 2 * A_BYTES;          // 64 KiB at f16x3, 32 KiB in the one-plane modes
+    constexpr int D = (163840 / STAGE) > 5 ? 5 : (163840 / STAGE);     // 2 stages at f16x3, 5 in the one-plane modes
+    constexpr int PW = STAGE / 4096;            // 1 KiB pieces per wave per stage (16 / 8)
+    constexpr int INFLIGHT = (D - 2) * PW;
+    constexpr int WT = 8, NPAIR = WT * WT;      // 8 x 8 accumulator tiles of 16 x 16 per wave
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
 
     int split, tile;
     if (a.xcd_map & 1) {
@@ -99,74 +104,67 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int tl = tile - pr.tile0;
     const int tm = tl / pr.nt, tn = tl - tm * pr.nt;
 
-    // this split's range of k-steps (16 time steps of one utterance each)
+    // this split's range of stages (32 time steps of one utterance each)
     int s_begin = (int)((long long)a.nstep * split / a.nsplit);
     int s_end = (int)((long long)a.nstep * (split + 1) / a.nsplit);
     const int nks = s_end - s_begin;
     if (a.xcd_map & 2) { s_begin = 0; s_end = nks; }   // measurement (WN_HWGRAD_DBG=1): every split re-reads the first range -> operands stay in L2
 
-    // ---- staging: each lane's source unit inside a piece (group gq, step tq), see the header comment ----------------
-    // unit u = lane of a piece holds (group g, step t) with u = 32 (t >> 3) + 8 g + ((t & 7) ^ 4 (g >> 1)): eight
-    // consecutive lanes fetch one whole 128-byte line (8 steps of a group), and the XOR spreads groups g and g + 2 over
-    // different banks for the transposed reads
-    const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
-    const unsigned lane_src = (unsigned)((gq * a.ld + tq) * 16);   // < 4 groups x ld x 16 B: fits 32 bits
-    // piece j of a plane = channel groups 4j..4j+3; wave w stages pieces w, w+4, ... : PW pieces per wave and stage, in the
-    // order (plane, j, A then B).  A stage's pieces are issued ONE AT A TIME between the MFMAs of a k-step (see the loop).
-    constexpr int JP = CH / 32 / 4;                 // pieces per plane and operand that one wave stages
-    static_assert(PW == P * JP * 2, "piece count");
+    // ---- staging: lane u of a piece fetches unit (group g, step t), see the header comment ---------------------------
+    const int su_g = (lane >> 3) & 1;
+    const int su_t = 8 * (2 * (lane >> 5) + ((lane >> 2) & 1)) + 4 * ((lane >> 4) & 1) + (lane & 3);
+    const unsigned lane_src = (unsigned)((su_g * a.ld + su_t) * 16);   // < 2 groups x ld x 16 B: fits 32 bits
+    // piece j of a plane = channel groups 2j, 2j+1 = operand tile j; wave w stages pieces w, w+4, w+8, w+12 of every
+    // (operand, plane): PW pieces per wave and stage, in the order (jj, plane, A then B).
     int is_step = s_begin;
     const char* is_a = nullptr;
     const char* is_b = nullptr;
     auto stage_sources = [&]() {                    // wave-uniform source bases of the stage to issue next
         const int sb = is_step / a.steps_per_row;
-        const int st = (is_step - sb * a.steps_per_row) * 16;
+        const int st = (is_step - sb * a.steps_per_row) * KT;
         is_a = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16;
         is_b = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16;
     };
-    auto issue_piece = [&](char* stage, auto pic) {      // stage = LDS image of the k-step being staged
+    auto issue_piece = [&](char* stage, auto pic) {      // stage = LDS image of the stage being filled
         constexpr int PI = decltype(pic)::value;
-        constexpr int pl = PI / (2 * JP), j = (PI % (2 * JP)) / 2;
+        constexpr int jj = PI / (2 * P), pl = (PI % (2 * P)) / 2;
         constexpr bool isB = (PI & 1) != 0;
-        const int piece = wave + 4 * j;
+        const int piece = wave + 4 * jj;
         // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay inside the
-        // tensor by re-reading its last four groups
+        // tensor by re-reading its last two groups
         if constexpr (!isB) {
-            const int ga = min(tm * (CH / 8) + 4 * piece, pr.a_groups - 4);
+            const int ga = min(tm * (CH / 8) + 2 * piece, pr.a_groups - 2);
             WN_GLDS(is_a + pl * pr.a_pstride + (long long)ga * a.ld * 16, lane_src, stage + pl * T_PLANE + piece * 1024);
         } else {
-            const int gb = min(tn * (CH / 8) + 4 * piece, pr.b_groups - 4);
+            const int gb = min(tn * (CH / 8) + 2 * piece, pr.b_groups - 2);
             WN_GLDS(is_b + pl * pr.b_pstride + (long long)gb * a.ld * 16, lane_src, stage + A_BYTES + pl * T_PLANE + piece * 1024);
         }
     };
-    auto issue_advance = [&]() { if (is_step + 1 < s_end) ++is_step; };   // past the end the last step is staged again
+    auto issue_advance = [&]() { if (is_step + 1 < s_end) ++is_step; };   // past the end the last stage is staged again
     auto issue_stage = [&](int slot) {
-#pragma unroll
-        for (int kk = 0; kk < KPS; ++kk) {
-            stage_sources();
-            char* stage = lds + slot * STAGE + kk * SUB;
-            [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(stage, std::integral_constant<int, I>{}), ...); }
-            (std::make_integer_sequence<int, PW>{});
-            issue_advance();
-        }
+        stage_sources();
+        char* stage = lds + slot * STAGE;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(stage, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, PW>{});
+        issue_advance();
     };
 
-    f32x16 acc[WT][WT];
+    f32x4 acc[WT][WT];
 #pragma unroll
     for (int m = 0; m < WT; ++m)
 #pragma unroll
         for (int n = 0; n < WT; ++n)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[m][n][q] = 0.0f;
+            for (int q = 0; q < 4; ++q) acc[m][n][q] = 0.0f;
     float rs[WT / 2];
 #pragma unroll
     for (int m = 0; m < WT / 2; ++m) rs[m] = 0.0f;
 
-    // transposed-read address of this lane inside a piece: 16-lane group sg -> channels 16 sg.., lane 4q+pp -> step q, channels 4pp..
-    const int sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
-    const int gr = 2 * sg + (pp >> 1);   // group of this lane's channels inside the 32-channel piece
-    const unsigned rd = (unsigned)((32 * h + 8 * gr + (q4 ^ (4 * (gr >> 1)))) * 16 + 8 * (pp & 1));   // steps 8h + q4; +4: XOR 4 units
-    const int hi_off = (gr >> 1) ? -64 : 64;   // steps 8h + 4 + q4: the unit index with bit 2 flipped
+    // transposed-read address of this lane inside a piece: k-block kb = lane >> 4 (steps 8 kb ..), lane 4 q4 + pp of the
+    // 16-lane group -> step q4 of the block's first / second four, channels 4 pp .. 4 pp + 3
+    const int kb = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned rd = (unsigned)((32 * (kb >> 1) + 8 * (pp >> 1) + 4 * (kb & 1) + q4) * 16 + 8 * (pp & 1));
+    constexpr int hi_off = 256;                    // steps + 4: unit index + 16
     const bool do_rs = pr.rowsum != 0;
 
     if (nks > 0) {
@@ -175,125 +173,107 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     }
 
     // ---- K loop ---------------------------------------------------------------------------------------------------
-    // Per k-step: counted wait + barrier, the transposed fragment reads of stage ks, then the MFMAs -- with the DMA pieces of
-    // stage ks + D - 1 issued ONE AT A TIME between the accumulator tiles, pinned by sched_barrier, so that their issue cost
-    // (~60 cycles each among MFMAs) hides in the MFMAs' shadow instead of delaying the first MFMA of the k-step.
-    // (A second variant that also double-buffered the fragments and read stage ks + 1 during the MFMAs of stage ks made
-    // hipcc move fragments into AGPRs and spill 81-124 registers; not kept.)
-    constexpr int NPAIR = WT * WT;
+    // Per stage: counted wait + barrier, then 64 accumulator tiles x (1 or 3) MFMAs with the transposed fragment reads just in
+    // time (two tiles ahead, sched_barrier-pinned) and the DMA pieces of the stage D - 1 ahead between the tiles.  With two
+    // stages (f16x3) the whole next stage is issued in the first half of the current one -- it has the second half to land;
+    // with five (one-plane modes) the pieces are spread evenly.
     int slot = 0;
-    for (int ks = 0; ks < nks; ks += KPS) {
+    for (int ks = 0; ks < nks; ++ks) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         __builtin_amdgcn_s_barrier();
         const int wslot = slot == 0 ? D - 1 : slot - 1;   // the previous stage's slot is free now
+        stage_sources();
+        char* wst = lds + wslot * STAGE;
+        const char* sa = lds + slot * STAGE + rd + (wm * WT) * 1024;
+        const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WT) * 1024;
+        u32x4 af[WT][P], bf[WT][P];
+        auto read_for = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < NPAIR) {
+                constexpr int m = t / WT, n = t % WT;
+                if constexpr (n == 0) {
 #pragma unroll
-        for (int kk = 0; kk < KPS; ++kk) {
-            stage_sources();
-            char* wst = lds + wslot * STAGE + kk * SUB;
-            const char* sa = lds + slot * STAGE + kk * SUB + rd + (wm * WT) * 1024;
-            const char* sbb = lds + slot * STAGE + kk * SUB + A_BYTES + rd + (wn * WT) * 1024;
-            // Fragments are read just in time, two accumulator tiles ahead of their first use (tile (m, n) first needs af[m] when
-            // n == 0 and bf[n] when m == 0), every step pinned by sched_barrier: left alone hipcc hoists all reads to the top and
-            // the k-step's first MFMA waits for most of them.  An odd step count leaves the last stage's second k-step unused
-            // (one-plane modes): its A fragments are ANDed to zero -- no branch around the MFMAs, which would turn every
-            // accumulator into a phi (see hgemm_kernel).
-            u32x4 af[WT][P], bf[WT][P];
-            const unsigned keep = (kk == 0 || ks + kk < nks) ? 0xffffffffu : 0u;
-            auto read_for = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t < NPAIR) {
-                    constexpr int m = t / WT, n = t % WT;
-                    if constexpr (n == 0) {
-#pragma unroll
-                        for (int pl = 0; pl < P; ++pl) {
-                            const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
-                            af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                            if constexpr (KPS > 1) af[m][pl] &= keep;
-                        }
-                    }
-                    if constexpr (m == 0) {
-#pragma unroll
-                        for (int pl = 0; pl < P; ++pl) {
-                            const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
-                            bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                        }
+                    for (int pl = 0; pl < P; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + m * 1024), hi = ds_read_tr16(sa + pl * T_PLANE + m * 1024 + hi_off);
+                        af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
                 }
-            };
-            read_for(std::integral_constant<int, 0>{});
-            read_for(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            [&]<int... I>(std::integer_sequence<int, I...>) {
-                ([&] {
-                    constexpr int idx = I, m = idx / WT, n = idx % WT;
-                    read_for(std::integral_constant<int, idx + 2>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (BF) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
-                    } else {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
-                        if constexpr (P == 2) {
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
-                        }
+                if constexpr (m == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < P; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + n * 1024), hi = ds_read_tr16(sbb + pl * T_PLANE + n * 1024 + hi_off);
+                        bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // DMA piece p after accumulator tile p * NPAIR / PW
-                    if constexpr ((idx * PW) % NPAIR == 0) {
-                        if (!(a.xcd_map & 4)) issue_piece(wst, std::integral_constant<int, idx * PW / NPAIR>{});
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }(), ...);
-            }(std::make_integer_sequence<int, NPAIR>{});
-            issue_advance();
-            if (do_rs) {   // row sums of A for two of this wave's row tiles (the other wave column takes the other two)
-#pragma unroll
-                for (int mm = 0; mm < WT / 2; ++mm) {
-                    const int m = wn * (WT / 2) + mm;   // wave-uniform, but must be a compile-time register index:
-#pragma unroll
-                    for (int mc = 0; mc < WT; ++mc)
-                        if (mc == m) {
-#pragma unroll
-                            for (int pl = 0; pl < P; ++pl)
-#pragma unroll
-                                for (int w = 0; w < 4; ++w) rs[mm] = dot_ones<BF>(af[mc][pl][w], rs[mm]);
-                        }
                 }
             }
-        }
+        };
+        read_for(std::integral_constant<int, 0>{});
+        read_for(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / WT, n = idx % WT;
+                read_for(std::integral_constant<int, idx + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BF) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, af[m][0]), __builtin_bit_cast(b8, bf[n][0]), acc[m][n], 0, 0, 0);
+                } else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    if constexpr (P == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr bool front = (D == 2);   // two stages: piece p after tile 2 p; otherwise spread over the stage
+                if constexpr (front ? (idx % 2 == 0 && idx / 2 < PW) : ((idx * PW) % NPAIR == 0)) {
+                    if (!(a.xcd_map & 4)) issue_piece(wst, std::integral_constant<int, front ? idx / 2 : idx * PW / NPAIR>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (n == WT - 1) {
+                    // row sums of A for four of this wave's eight row tiles (the other wave column takes the other four)
+                    if (do_rs && (m >> 2) == wn) {
+#pragma unroll
+                        for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) rs[m & 3] = dot_ones<BF>(af[m][pl][w], rs[m & 3]);
+                    }
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        issue_advance();
         slot = slot + 1 == D ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- write this split's partial tile -----------------------------------------------------------------------------
+    // C/D layout of v_mfma_f32_16x16x32: column = lane & 15, rows 4 (lane >> 4) + q
     float* out = a.slab + (long long)split * a.slab_floats + pr.slab_off;
 #pragma unroll
     for (int m = 0; m < WT; ++m)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = tm * CH + wm * 32 * WT + 32 * m + (q & 3) + 8 * (q >> 2) + 4 * h;
-            float* prow = out + (long long)row * pr.Np + tn * CH + wn * 32 * WT + r;
+        for (int q = 0; q < 4; ++q) {
+            const int row = tm * CH + wm * 16 * WT + 16 * m + 4 * kb + q;
+            float* prow = out + (long long)row * pr.Np + tn * CH + wn * 16 * WT + (lane & 15);
 #pragma unroll
-            for (int n = 0; n < WT; ++n) prow[32 * n] = acc[m][n][q];
+            for (int n = 0; n < WT; ++n) prow[16 * n] = acc[m][n][q];
         }
     if (do_rs && tn == 0) {
 #pragma unroll
         for (int mm = 0; mm < WT / 2; ++mm) {
-            const float tot = rs[mm] + __shfl_xor(rs[mm], 32);
-            const int row = tm * CH + wm * 32 * WT + 32 * (wn * (WT / 2) + mm) + r;
-            if (h == 0) a.rowsum[(long long)split * a.rs_floats + pr.rs_off + row] = tot;
+            float tot = rs[mm] + __shfl_xor(rs[mm], 16);   // the four k-blocks of a row live in lanes l, l+16, l+32, l+48
+            tot += __shfl_xor(tot, 32);
+            const int row = tm * CH + wm * 16 * WT + 16 * (wn * (WT / 2) + mm) + (lane & 15);
+            if (lane < 16) a.rowsum[(long long)split * a.rs_floats + pr.rs_off + row] = tot;
         }
     }
 }
 
-hipError_t launch_hwgrad(int prec, const HWgradArgs& a, int WT, hipStream_t st);
-
-template <int WT>
 static hipError_t launch_hw(int prec, const HWgradArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)(a.ntile_total * a.nsplit)), block(256);
-    if (prec == HP_F16X3) hipLaunchKernelGGL((hwgrad_kernel<WT, 2, false>), grid, block, 0, st, a);
-    else if (prec == HP_F16) hipLaunchKernelGGL((hwgrad_kernel<WT, 1, false>), grid, block, 0, st, a);
-    else if (prec == HP_BF16) hipLaunchKernelGGL((hwgrad_kernel<WT, 1, true>), grid, block, 0, st, a);
+    if (prec == HP_F16X3) hipLaunchKernelGGL((hwgrad_kernel<2, false>), grid, block, 0, st, a);
+    else if (prec == HP_F16) hipLaunchKernelGGL((hwgrad_kernel<1, false>), grid, block, 0, st, a);
+    else if (prec == HP_BF16) hipLaunchKernelGGL((hwgrad_kernel<1, true>), grid, block, 0, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -304,9 +284,9 @@ hipError_t launch_hwgrad(int prec, const HWgradArgs& a, hipStream_t st) {
     if (dbg) {
         HWgradArgs b = a;
         b.xcd_map |= 2 * dbg;
-        return launch_hw<4>(prec, b, st);
+        return launch_hw(prec, b, st);
     }
-    return launch_hw<4>(prec, a, st);
+    return launch_hw(prec, a, st);
 }
 
 }  // namespace wn
