@@ -3,6 +3,8 @@ one-hot path and the oracle (reference: modules/wavenet.py:54,93 with the one-ho
 import pytest
 import torch
 
+import wavenet_speech_amd as W
+
 from oracle import wavenet_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -75,5 +77,9 @@ def test_embed_backward_is_deterministic_and_rejects_bad_levels(mode, monkeypatc
     for bad in (256, -1):
         q3 = q.clone()
         q3[1, 77] = bad
+        with torch.no_grad():                            # inference call: refused at once
+            with pytest.raises(RuntimeError, match="level outside"):
+                HF.embed_conv(q3, w, b)
+        HF.embed_conv(q3, w, b)                          # training call: the counter travels without stalling the stream ...
         with pytest.raises(RuntimeError, match="level outside"):
-            HF.embed_conv(q3, w, b)
+            W.check_device_flags()                       # ... and is reported by the next call or on request

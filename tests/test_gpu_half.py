@@ -126,14 +126,25 @@ def test_half_inference_matches_training_forward_and_is_deterministic():
 
 
 def test_fp16_overflow_is_loud():
-    """fp16 holds the residual stream up to 16 * 65504: beyond that the call must fail, not return inf/garbage"""
+    """fp16 holds the residual stream up to 16 * 65504: beyond that the call must fail, not return inf/garbage -- at once
+    for an inference call, by the next call into the stack (or check_fp16_overflow()) for a training call, whose flag is
+    read without stalling the stream"""
     c = 32
     layers = [(c, c, 2, 1), (c, c, 2, 2)]
     net = _cond_wavenet(c, layers, seed=13).to(DEV)
     W.set_precision(net, "f16x3")
     x = torch.randn(1, c, 100, device=DEV) * 3e6
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="overflow"):
+            net(x)
+    net(x)                                               # training call: returns, the flag travels asynchronously
     with pytest.raises(RuntimeError, match="overflow"):
-        net(x)
+        W.check_fp16_overflow()
+    net(x)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="overflow"):  # ... and the next call into the stack reports it
+        net(torch.randn(1, c, 100, device=DEV))
+    W.check_fp16_overflow()                              # nothing left pending
     W.set_precision(net, "bf16")
     assert bool(torch.isfinite(net(x)).all())
 

@@ -12,5 +12,7 @@ from . import functional, modules, series  # noqa: F401
 from .modules import (CausalConv1d, NonCausalConv1d, RawCTCNet, ResidualBlock, WaveNet,  # noqa: F401
                       WaveNetClassifier)
 from .modules.block import set_precision  # noqa: F401
+from ._flags import check_device_flags  # noqa: F401
+from .functional_half import check_fp16_overflow  # noqa: F401
 
 __version__ = "0.1.0"

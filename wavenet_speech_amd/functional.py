@@ -11,7 +11,7 @@ import os
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _flags, _lib
 from .series import Lease, SeriesLayout, fresh_series, load_series, window
 
 PARAMS_PER_BLOCK = 10  # order = _lib.BlockParams fields
@@ -405,7 +405,7 @@ class _SequenceNLLFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, logits, target):
+    def forward(ctx, logits, target, grad_enabled=True):
         lib = _lib.load()
         _require_device(logits, "logits")
         if target.dtype != torch.int64 or not target.is_cuda:
@@ -417,12 +417,12 @@ class _SequenceNLLFn(torch.autograd.Function):
         partial = torch.empty(lib.wn_nll_partials(B, L), dtype=torch.float32, device=x.device)
         bad = torch.zeros(1, dtype=torch.int32, device=x.device)
         _lib.check(lib.wn_nll_forward(_p(x), _p(tg), _p(lse), _p(partial), _p(bad), B, C, L, _stream()), "wn_nll_forward")
-        # the kernel never indexes the logits with an out-of-range label (it counts it and poisons the loss with NaN);
-        # turning the count into an exception costs one device->host read per call (WN_NLL_CHECK=0 skips it)
+        # the kernel never indexes the logits with an out-of-range label (it counts it and poisons the loss with NaN); the count
+        # becomes an exception without stalling the stream in training calls (see _flags.py; WN_NLL_CHECK=0 skips it)
         if os.environ.get("WN_NLL_CHECK", "1") != "0":
-            nbad = int(bad.item())
-            if nbad:
-                raise RuntimeError("wavenet_speech_amd: sequence_nll got %d target(s) outside [0, %d)" % (nbad, C))
+            _flags.WATCH.poll()
+            _flags.WATCH.note(bad, lambda n, C=C: "wavenet_speech_amd: sequence_nll got %d target(s) outside [0, %d)" % (n, C),
+                              at_once=not (grad_enabled and ctx.needs_input_grad[0]))
         ctx.save_for_backward(x, tg, lse)
         return partial.sum() / B
 
@@ -436,11 +436,11 @@ class _SequenceNLLFn(torch.autograd.Function):
         gscale = (g / B).to(torch.float32).reshape(1).contiguous()
         dx = torch.empty_like(x)
         _lib.check(lib.wn_nll_backward(_p(x), _p(tg), _p(lse), _p(gscale), _p(dx), B, C, L, _stream()), "wn_nll_backward")
-        return dx, None
+        return dx, None, None
 
 
 def sequence_nll(logits, target):
-    return _SequenceNLLFn.apply(logits, target)
+    return _SequenceNLLFn.apply(logits, target, torch.is_grad_enabled())
 
 
 class _EmbedConvFn(torch.autograd.Function):
@@ -449,7 +449,7 @@ class _EmbedConvFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, weight, bias, levels):
+    def forward(ctx, weight, bias, levels, grad_enabled=True):
         lib = _lib.load()
         _require_device(weight, "weight")
         if levels.dtype != torch.int64 or not levels.is_cuda or levels.dim() != 2:
@@ -463,9 +463,9 @@ class _EmbedConvFn(torch.autograd.Function):
         bad = torch.zeros(1, dtype=torch.int32, device=weight.device)
         _lib.check(lib.wn_embed_forward(_p(q), _p(w), _p(b), _p(y), B, L, classes, Co, k, _p(bad), _stream()), "wn_embed_forward")
         if os.environ.get("WN_NLL_CHECK", "1") != "0":
-            nbad = int(bad.item())
-            if nbad:
-                raise RuntimeError("wavenet_speech_amd: %d thread(s) saw a level outside [0, %d)" % (nbad, classes))
+            _flags.WATCH.poll()
+            _flags.WATCH.note(bad, lambda n, classes=classes: "wavenet_speech_amd: %d thread(s) saw a level outside [0, %d)" % (n, classes),
+                              at_once=not (grad_enabled and any(ctx.needs_input_grad)))
         ctx.save_for_backward(q)
         ctx.dims, ctx.has_bias = (B, L, classes, Co, k), bias is not None
         return y
@@ -488,7 +488,7 @@ class _EmbedConvFn(torch.autograd.Function):
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
             _lib.check(lib.wn_embed_backward(_p(q), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, B, L, classes, Co, k, _stream()),
                        "wn_embed_backward")
-            return dw, db, None
+            return dw, db, None, None
         # default: the exact-fp32 weight-gradient GEMM (wgrad_kernel, fixed summation order) against a one-hot that exists only
         # inside this call -- the forward pass and the saved state never hold one
         layout = SeriesLayout(L, k - 1)
@@ -501,12 +501,12 @@ class _EmbedConvFn(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
         _lib.check(lib.wn_conv_backward_weights(ctypes.byref(shape), _p(xin), _p(dyl), _p(dw), _p(db), _p(ws), ws_bytes,
                                                 _stream()), "wn_conv_backward_weights")
-        return dw, db, None
+        return dw, db, None, None
 
 
 def embed_conv(levels, weight, bias):
     """entry_conv1d(one_hot(levels)) without the one-hot: levels [B, L] int64 -> [B, Co, L]"""
-    return _EmbedConvFn.apply(weight, bias, levels)
+    return _EmbedConvFn.apply(weight, bias, levels, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ import os
 import torch
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _flags, _lib
 from .functional import PARAMS_PER_BLOCK, _on_device_of_first_tensor, _p, _params_struct, _prep_params, _require_device, _stream
 from .series import Lease
 
@@ -61,10 +61,13 @@ def _shape(spec, batch, layout):
                            layout.ld, layout.halo)
 
 
-def _check_overflow(flag, what):
-    if flag is not None and int(flag.item()):
-        raise RuntimeError("wavenet_speech_amd: fp16 overflow in the %s of the half-precision stack (a value beyond +-65504 "
-                           "after the built-in 1/16 residual scaling); use precision='f32' or 'bf16' for this model" % what)
+_OVERFLOW_MSG = ("wavenet_speech_amd: fp16 overflow in the %s of the half-precision stack (a value beyond +-65504 after the "
+                 "built-in 1/16 residual scaling); use precision='f32' or 'bf16' for this model")
+
+
+def check_fp16_overflow():
+    """wait for every outstanding device flag (see _flags.py) and raise if one is set"""
+    _flags.check_device_flags()
 
 
 def _load(lib, mode, dense, lease, layout, scale, dyn, flag):
@@ -81,6 +84,7 @@ class _HalfStackFn(torch.autograd.Function):
     def forward(ctx, x, specs, mode, grad_enabled, pack_cache, *flat):
         lib = _lib.load()
         _require_device(x, "input")
+        _flags.WATCH.poll()
         n = len(specs)
         assert len(flat) == n * PARAMS_PER_BLOCK
         B, C0, L = x.shape
@@ -152,7 +156,7 @@ class _HalfStackFn(torch.autograd.Function):
                                                 _p(packed), _stream()), "wn_hskipsum_pack")
                 _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
                                                    0 if g0 == 0 else 1, _stream()), "wn_hskipsum_forward")
-        _check_overflow(flag, "forward pass")
+        _flags.WATCH.note(flag, _OVERFLOW_MSG % "forward pass", at_once=not training)
         ctx.specs, ctx.saved, ctx.layout, ctx.batch, ctx.mode = specs, saved, layout, B, mode
         ctx.param_shapes = [tuple(t.shape) for t in flat]
         return S
@@ -162,6 +166,7 @@ class _HalfStackFn(torch.autograd.Function):
     @_on_device_of_first_tensor
     def backward(ctx, d_skips):
         lib = _lib.load()
+        _flags.WATCH.poll()
         specs, layout, B, mode = ctx.specs, ctx.layout, ctx.batch, ctx.mode
         dev = d_skips.device
         d_skips = d_skips.contiguous()
@@ -201,7 +206,7 @@ class _HalfStackFn(torch.autograd.Function):
             grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
             dr = dx
             ctx.saved[l] = None
-        _check_overflow(flag, "backward pass")
+        _flags.WATCH.note(flag, _OVERFLOW_MSG % "backward pass", at_once=False)
         grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
         return (dx0, None, None, None, None) + tuple(grads_flat)
 

@@ -60,9 +60,10 @@ class _CTCFn(torch.autograd.Function):
             bad = torch.zeros(1, dtype=torch.int32, device=dev)
             _lib.check(lib.wn_ctc_loss(_p(x), _p(labels), _p(label_lengths), _p(in_len), B, C, T, lmax, int(blank), _p(nll),
                                        _p(dx), _p(ws), ws_bytes, _p(bad), _stream()), "wn_ctc_loss")
-            if int(bad.item()):
-                raise RuntimeError("wavenet_speech_amd: ctc labels outside [0, %d), equal to the blank (%d), or lengths out of "
-                                   "range in %d utterance(s)" % (C, blank, int(bad.item())))
+            from . import _flags
+            _flags.WATCH.poll()
+            _flags.WATCH.note(bad, lambda n, C=C, blank=blank: "wavenet_speech_amd: ctc labels outside [0, %d), equal to the blank "
+                              "(%d), or lengths out of range in %d utterance(s)" % (C, blank, n), at_once=not need_grad)
         ctx.dx = dx
         return nll.sum()
 
