@@ -107,6 +107,39 @@ def test_plain_half_modes_vs_oracle(precision):
     print(precision, {k: "%.1e" % v for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]})
 
 
+@pytest.mark.parametrize("precision,c,dims,L,B", [("f16x3", 256, (1, 2, 64), 384, 2), ("f16x3", 128, (1, 3), 256, 3),
+                                                  ("f16", 256, (1, 4), 256, 2), ("bf16", 256, (2, 1), 384, 1),
+                                                  ("f16x3", 512, (1, 130), 128, 1)])
+def test_full_tile_shapes_take_the_16x16x32_gemm(precision, c, dims, L, B):
+    """rows a multiple of 256 (gate: channels a multiple of 128) and L a multiple of 128 select hgemm8_kernel in the f16x3 mode
+    (256 x 128 tiles on v_mfma_f32_16x16x32, 32-channel k-steps, its own weight packing): all four epilogues against the
+    oracle.  The one-plane modes stay on hgemm_kernel for these shapes unless WN_HGEMM16=2 (test_one_plane_modes_on_the_
+    16x16x32_gemm runs them in a child process); WN_HGEMM16=0 keeps every shape on hgemm_kernel."""
+    layers = [(c, c, 2, d) for d in dims]
+    net = _cond_wavenet(c, layers, seed=c + L)
+    g = torch.Generator().manual_seed(L + B)
+    x, cot = torch.randn(B, c, L, generator=g), torch.randn(B, c, L, generator=g)
+    _run(net, x, cot, layers, precision, TOL if precision == "f16x3" else LOOSE[precision])
+    # inference (no saved tanh / sigmoid, per-block skip accumulation on the other kernel) agrees with the training forward
+    net = net.to(DEV)
+    with torch.no_grad():
+        y_eval = net(x.to(DEV))
+    y_train = net(x.to(DEV)).detach()
+    assert O.rel_err(y_eval.cpu(), y_train.cpu()) < (1e-5 if precision == "f16x3" else 2e-2)
+
+
+def test_one_plane_modes_on_the_16x16x32_gemm():
+    """hgemm8_kernel's f16 / bf16 instantiations are not selected by default (slower there); force them in a child process"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WN_HGEMM16="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_half.py"), "-q", "-x", "-k",
+                        "full_tile and (f16-256 or bf16-256)"], env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+
+
 def test_half_inference_matches_training_forward_and_is_deterministic():
     c = 64
     layers = [(c, c, 2, 2 ** i) for i in range(5)]

@@ -94,6 +94,7 @@ struct HPackArgs {
     int slab_boff[kHMaxSlab];
     int nslab, rows;                // rows per slab (64 * MT)
     int planes, bf16;
+    int kgroups, _pad2;             // k-groups of 8 channels per k-step: 2 (hgemm_kernel) or 4 (hgemm8_kernel); seg_nks in those k-steps
     char* wpacked;
     float* bias;
     long long total_units;          // 16-byte units per plane over all slabs

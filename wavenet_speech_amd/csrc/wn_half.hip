@@ -166,15 +166,16 @@ hipError_t launch_hload(const HLoadArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = one 16-byte unit of plane 0 (+ plane 1)
     if (idx < a.total_units) {
-        const long long plane_bytes = 2LL * a.rows * 16;               // one k-step of one plane
+        const int KG = a.kgroups;
+        const long long plane_bytes = (long long)KG * a.rows * 16;     // one k-step of one plane
         const long long kstep_bytes = plane_bytes * a.planes;
         int slab = 0;
         while (slab + 1 < a.nslab && idx * 16 * a.planes >= a.slab_woff[slab + 1]) ++slab;
         const long long rel = idx - a.slab_woff[slab] / (16 * a.planes);   // unit index inside the slab, plane 0 numbering
         const int row = (int)(rel % a.rows);
-        const long long kk = rel / a.rows;                             // 2*ks + kg
-        const int kg = (int)(kk & 1);
-        long long ks = kk >> 1;
+        const long long kk = rel / a.rows;                             // KG * ks + kg
+        const int kg = (int)(kk % KG);
+        long long ks = kk / KG;
         const long long ks_abs = ks;
         int s = 0;
         while (ks >= a.seg_nks[s]) { ks -= a.seg_nks[s]; ++s; }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
             if (src.ptr && r < src.rows) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int c = 16 * (int)ks + 8 * kg + j;
+                    const int c = 8 * KG * (int)ks + 8 * kg + j;
                     if (c < src.cols) v[j] = src.ptr[(long long)r * src.stride_r + (long long)c * src.stride_c] * src.scale;
                 }
             }
@@ -690,6 +691,299 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32: 256 x 128 tiles, EIGHT waves, one workgroup per CU
+// ---------------------------------------------------------------------------------------------------------------
+// The half path runs at the chip's power limit and the 16x16x32 shape sustains a higher clock than 32x32x16 at equal cycles per
+// FLOP (tools/probes/hwgrad_loop.hip: 2.2 vs 1.75 GHz).  Its contraction depth is 32 channels, so a stage holds 32 channels:
+// 48 KiB at f16x3 for a 256 x 128 tile -- a three-stage ring takes most of the LDS and there is no room for a second workgroup.
+// Instead ONE workgroup of eight waves (4 x 2, each 64 rows x 64 columns = 4 x 4 accumulator tiles of 16 x 16, 64 registers)
+// keeps two waves on every SIMD.  Used for FULL tiles only (rows a multiple of 256, L a multiple of 128: the plan decides,
+// HPlan::init); everything else stays on hgemm_kernel.  Weights are packed [k-step of 32][plane][k-group 4][row 256][8].
+constexpr int kHCol8 = 128;
+
+template <int P, bool BF, int EPI>
+__global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
+    constexpr int ROWS = 256, COLS = kHCol8;
+    constexpr int A_PLANE = 4 * ROWS * 16, B_PLANE = 4 * COLS * 16;
+    constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;   // 48 KiB at f16x3, 24 KiB one plane
+    constexpr int D = (163840 / STAGE) > 6 ? 6 : (163840 / STAGE);                            // 3 / 6 stages
+    constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192;                               // 1 KiB pieces per wave and stage
+    constexpr int PW = A_PW + B_PW;
+    constexpr int INFLIGHT = (D - 2) * PW;
+    constexpr int NPAIR = 16;
+    static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
+    static_assert(B_PW >= 1, "piece split");
+    __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
+    typedef typename HT<BF>::v8 V8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c16 = lane & 15, rq = lane >> 4;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int slab_i = local % a.nslab;
+    const int coltile = (local / a.nslab) * 8 + xcd;
+    if (coltile >= a.ncol) return;
+    const int b = coltile / a.tiles_per_row;
+    const int t0 = (coltile - b * a.tiles_per_row) * COLS;
+    const HSlab sl = a.slab[slab_i];
+    const int ld = a.ld;
+
+    int nks = 0;
+    for (int s = 0; s < sl.nseg; ++s) nks += a.seg[s].nks >> 1;   // segments are whole numbers of 32-channel k-steps
+    if (a.dbg & 1) nks = 1;
+
+    const char* a_src = a.wpacked + sl.woff;
+    int is_ks = 0;
+    int is_seg = 0, is_left = a.seg[0].nks >> 1;
+    long long is_pstride = a.seg[0].pstride;
+    const long long unit0 = (long long)a.halo + t0;
+    const char* b_src = a.seg[0].base + (long long)b * a.seg[0].ustride + (unit0 + a.seg[0].off) * 16;
+    const unsigned lane16 = lane * 16u;
+
+    auto issue_piece = [&](char* stage, auto pic) {
+        constexpr int PI = decltype(pic)::value;
+        if constexpr (PI < A_PW) {
+            const int piece = wave + 8 * PI;                                  // the weight image of a stage is contiguous
+            WN_GLDS(a_src + (long long)is_ks * A_BYTES + piece * 1024, lane16, stage + piece * 1024);
+        } else {
+            const int q = wave + 8 * (PI - A_PW);                             // (plane, k-group, column half)
+            const int hc = q & 1, kg = (q >> 1) & 3, p = q >> 3;
+            WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + hc * 1024, lane16,
+                    stage + A_BYTES + ((p * 4 + kg) * COLS + 64 * hc) * 16);
+        }
+    };
+    auto issue_advance = [&]() {
+        if (is_ks + 1 < nks) {
+            ++is_ks;
+            b_src += 4LL * ld * 16;
+            if (--is_left == 0) {
+                ++is_seg;
+                const HSeg ns = a.seg[is_seg];
+                is_left = ns.nks >> 1;
+                is_pstride = ns.pstride;
+                b_src = ns.base + (long long)b * ns.ustride + (unit0 + ns.off) * 16;
+            }
+        }
+    };
+    auto issue = [&](int slot) {
+        char* stage = lds + slot * STAGE;
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(stage, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, PW>{});
+        issue_advance();
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][n][q] = 0.0f;
+
+    // biases of this lane's rows (16 m + 4 rq + 0..3), fetched before the K loop (see hgemm_kernel)
+    f32x4 bvec[4];
+    if constexpr (EPI != HEPI_DGATE) {
+        const float* bias_p = (a.bias ? a.bias + sl.boff : reinterpret_cast<const float*>(a.wpacked + sl.woff)) + wm * 64 + 4 * rq;
+        const bool has_bias = a.bias != nullptr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bias_p + 16 * m);
+            bvec[m] = has_bias ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) issue(s);
+
+    // fragment of v_mfma_f32_16x16x32: lane (c16, rq) holds row / column c16, k = 8 rq .. 8 rq + 7 = k-group rq of the stage
+    const unsigned a_rd = (unsigned)((rq * ROWS + wm * 64 + c16) * 16);
+    const unsigned b_rd = (unsigned)(A_BYTES + (rq * COLS + wn * 64 + c16) * 16);
+
+    int slot = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int wslot = slot == 0 ? D - 1 : slot - 1;
+        const char* st = lds + slot * STAGE;
+        char* wst = lds + wslot * STAGE;
+        V8 af[4][P], bf[4][P];
+        auto read_for = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < NPAIR) {
+                constexpr int m = t / 4, n = t % 4;
+                if constexpr (n == 0) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 256);
+                }
+                if constexpr (m == 0) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) bf[n][p] = *reinterpret_cast<const V8*>(st + b_rd + p * B_PLANE + n * 256);
+                }
+            }
+        };
+        read_for(std::integral_constant<int, 0>{});
+        read_for(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / 4, n = idx % 4;
+                read_for(std::integral_constant<int, idx + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BF) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                } else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][0], bf[n][0], acc[m][n], 0, 0, 0);
+                    if constexpr (P == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][0], bf[n][1], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][1], bf[n][0], acc[m][n], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                    ([&] {
+                        if constexpr ((Q * NPAIR) / PW == idx) {
+                            issue_piece(wst, std::integral_constant<int, Q>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, PW>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        issue_advance();
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dbg & 2) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum += acc[m][n][q];
+        if (sum == 1.2345e-30f && a.flag) a.flag[0] = 7;
+        return;
+    }
+
+    // ---- epilogue (full tiles only: straight-line code) ---------------------------------------------------------------
+    // C/D layout of the 16x16 tile: column = lane & 15, rows 4 (lane >> 4) + q: four consecutive channels = one 8-byte piece
+    // of the unit (group 2 m + (rq >> 1) of the wave's eight, half rq & 1).
+    const float osc = a.oscale;
+    unsigned ovf = 0;
+    const long long col = ((long long)a.halo + t0 + wn * 64 + c16) * 16 + 8 * (rq & 1);
+    if constexpr (EPI == HEPI_STORE) {
+        const HDst d = a.dst[sl.dst];
+        char* dbase = d.base + (long long)b * d.ustride + col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            char* prow = dbase + (long long)(2 * m) * ld * 16;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[m][n][q] * osc + bvec[m][q];
+                store4<P, BF>(prow + n * 256, d.pstride, v, ovf);
+            }
+        }
+    } else if constexpr (EPI == HEPI_GATE) {
+        // tile rows 0..31 of a wave are a, 32..63 are g of the same 32 channels: pairs (m, m + 2)
+        const long long o0 = col + (long long)(((sl.row0 + wm * 32) >> 3) + (rq >> 1)) * ld * 16;
+        char* zb = a.z.base + (long long)b * a.z.ustride + o0;
+        const bool keep = a.ta.base != nullptr;
+        char* tb = keep ? a.ta.base + (long long)b * a.ta.ustride + o0 : zb;
+        char* sb = keep ? a.sg.base + (long long)b * a.sg.ustride + o0 : zb;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float vt[4], vs[4], vz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    vt[q] = h_tanh(acc[m][n][q] * osc + bvec[m][q]);
+                    vs[q] = h_sigmoid(acc[m + 2][n][q] * osc + bvec[m + 2][q]);
+                    vz[q] = vt[q] * vs[q];
+                }
+                const long long on = (long long)(2 * m) * ld * 16 + n * 256;
+                store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
+                if (keep) {
+                    store4<P, BF, false>(tb + on, a.ta.pstride, vt, ovf);
+                    store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
+                }
+            }
+    } else if constexpr (EPI == HEPI_DGATE) {
+        typedef typename HT<BF>::v4 V4;
+        const long long o0 = col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
+        const char* tab = a.ta.base + (long long)b * a.ta.ustride + o0;
+        const char* sgb = a.sg.base + (long long)b * a.sg.ustride + o0;
+        char* dab = a.da.base + (long long)b * a.da.ustride + o0;
+        char* dgb = a.dg.base + (long long)b * a.dg.ustride + o0;
+        V4 rt[2][4][P], rs[2][4][P];                       // raw tanh / sigmoid of a 16-row tile, one tile ahead
+        auto fetch = [&](int m, V4 (&ft)[4][P], V4 (&fs)[4][P]) {
+            const long long o = (long long)(2 * m) * ld * 16;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 256 + p * a.ta.pstride);
+                    fs[n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 256 + p * a.sg.pstride);
+                }
+        };
+        fetch(0, rt[0], rs[0]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m + 1 < 4) fetch(m + 1, rt[(m + 1) & 1], rs[(m + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const long long o = (long long)(2 * m) * ld * 16;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float va[4], vg[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t_ = (float)rt[m & 1][n][0][q], s_ = (float)rs[m & 1][n][0][q];
+                    if constexpr (P == 2) { t_ += (float)rt[m & 1][n][1][q]; s_ += (float)rs[m & 1][n][1][q]; }
+                    const float dz = acc[m][n][q] * osc;
+                    va[q] = dz * s_ * (1.0f - t_ * t_);
+                    vg[q] = dz * t_ * s_ * (1.0f - s_);
+                }
+                store4<P, BF>(dab + o + n * 256, a.da.pstride, va, ovf);
+                store4<P, BF>(dgb + o + n * 256, a.dg.pstride, vg, ovf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {   // HEPI_F32: dense fp32 [B][rows][L], no accumulate (the plan keeps accumulating launches on hgemm_kernel)
+        const float dsc = osc * (a.dyn_inv ? a.dyn_inv[0] : 1.0f);
+        float* pbase = a.out32 + ((long long)b * a.out32_rows + sl.row0 + wm * 64 + 4 * rq) * a.L + t0 + wn * 64 + c16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float* prow = pbase + (long long)(16 * m + q) * a.L;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q];
+            }
+    }
+    if constexpr (!BF) {
+        if (ovf && a.flag) atomicOr(a.flag, 1u);
+    }
+}
+
+template <int P, bool BF>
+static hipError_t launch_h8(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
+    switch (epi) {
+        case HEPI_STORE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_STORE>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32>), dim3(grid), dim3(512), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int MT, int P, bool BF>
 static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
     static const bool report = getenv("WN_HGEMM_OCCUPANCY") != nullptr;   // measurement: print the occupancy API's answer once
@@ -724,6 +1018,16 @@ hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStr
     HGemmArgs a = a_in;
     static const int dbg = getenv("WN_HGEMM_DBG") ? atoi(getenv("WN_HGEMM_DBG")) : 0;
     a.dbg = dbg;
+    if (MT == 8) {   // hgemm8_kernel: the plan guarantees full 256 x 128 tiles
+        if (a.L % kHCol8 != 0) return hipErrorInvalidValue;
+        a.tiles_per_row = a.L / kHCol8;
+        a.ncol = a.B * a.tiles_per_row;
+        const unsigned grid8 = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));
+        if (prec == HP_F16X3) return launch_h8<2, false>(epi, a, grid8, st);
+        if (prec == HP_F16) return launch_h8<1, false>(epi, a, grid8, st);
+        if (prec == HP_BF16) return launch_h8<1, true>(epi, a, grid8, st);
+        return hipErrorInvalidValue;
+    }
     a.tiles_per_row = (a.L + kHCol - 1) / kHCol;
     a.ncol = a.B * a.tiles_per_row;
     const unsigned grid = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));

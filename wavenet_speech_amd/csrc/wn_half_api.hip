@@ -74,6 +74,7 @@ HDst dst_of(const HView& v) { HDst d; d.base = v.base; d.ustride = v.ustride; d.
 // ---- GEMM plans -------------------------------------------------------------------------------------------------
 struct HPlan {
     int MT = 4, rows = 256, nslab = 0, nseg = 0, planes = 1;
+    int k32 = 0;        // 1: hgemm8_kernel (v_mfma 16x16x32, 256 x 128 tiles, 32-channel k-steps); weights packed for it
     int seg_nks[kMaxSeg] = {0};
     long long slab_woff[kHMaxSlab] = {0};
     int slab_nseg[kHMaxSlab] = {0}, slab_row0[kHMaxSlab] = {0}, slab_boff[kHMaxSlab] = {0};
@@ -84,11 +85,21 @@ struct HPlan {
     //            store bursts (gate writes three tensors) that overlap the other workgroup's K loop: gate 0.510 -> 0.467 ms,
     //            dz 0.370 -> 0.302, res 0.242 -> 0.229, dx 0.413 -> 0.403
     //   long_k = true  (skips_sum, K = 30 C): 256-row tiles, one workgroup per CU -- half the weight re-staging: 2.20 vs 2.53 ms
-    void init(int out_rows, int planes_, bool long_k = false) {
-        MT = (long_k && out_rows > 128) ? 4 : 2;
+    //   hgemm8_kernel (k32): the 16x16x32 MFMA shape sustains a higher clock at the power limit; it takes FULL 256 x 128 tiles
+    //            only, so it is chosen when the row count is a multiple of 256 and L a multiple of 128 (cfg3, cfg5; WN_HGEMM16=0
+    //            turns it off for A/B runs).  Launches that accumulate into their output stay on hgemm_kernel.
+    void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool allow_k32 = false) {
+        static const bool k32_on = !(getenv("WN_HGEMM16") && atoi(getenv("WN_HGEMM16")) == 0);
+        // f16x3 only: measured at cfg3 245.7 vs 238.8 samples/s with it; in the one-plane modes (16 MFMAs per wave between
+        // barriers) it loses: cfg5 f16 89.1 vs 84.7 ms/step.  WN_HGEMM16=2 forces it on there too (tests).
+        static const bool k32_all = getenv("WN_HGEMM16") && atoi(getenv("WN_HGEMM16")) == 2;
+        k32 = (allow_k32 && k32_on && (planes_ == 2 || k32_all) && out_rows % 256 == 0 && length > 0 && length % 128 == 0) ? 1 : 0;
+        MT = (k32 || (long_k && out_rows > 128)) ? 4 : 2;
         rows = 64 * MT;
         planes = planes_;
     }
+    int kernel() const { return k32 ? 8 : MT; }              // what launch_hgemm is told
+    int wave_rows() const { return k32 ? 4 : 2; }            // wave rows of the workgroup (each wave owns rows / wave_rows rows)
     bool add_slab(int nseg_used, int row0) {
         if (nslab >= kHMaxSlab) return false;
         const int s = nslab++;
@@ -116,7 +127,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     {   // FA: [a ; g] interleaved in 32-channel tile pairs; K = k taps of x
         HPlan& g = p.fa;
-        g.init(2 * Co, P);
+        g.init(2 * Co, P, false, s->length, true);
         g.nseg = k;
         for (int j = 0; j < k; ++j) g.seg_nks[j] = cp32(Ci) / 16;
         const int ch_per_slab = g.rows / 2;
@@ -124,7 +135,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // FR: r rows contract [z ; x]
         HPlan& g = p.fr;
-        g.init(Co, P);
+        g.init(Co, P, false, s->length, true);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Co) / 16;
         g.seg_nks[1] = cp32(Ci) / 16;
@@ -139,7 +150,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KA: dz rows (z channels) contract [dskip ; dr]
         HPlan& g = p.ka;
-        g.init(Co, P);
+        g.init(Co, P, false, s->length, true);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Ms) / 16;
         g.seg_nks[1] = cp32(Co) / 16;
@@ -147,7 +158,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KB: dx rows (input channels) contract [da_0; dg_0; ...; dr]
         HPlan& g = p.kb;
-        g.init(Ci, P);
+        g.init(Ci, P, false, s->length, true);
         g.nseg = 2 * k + 1;
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
@@ -167,7 +178,8 @@ void fill_hpack(HPackArgs& a, const HPlan& g, void* packed, size_t off, int prec
     a.rows = g.rows;
     a.planes = g.planes;
     a.bf16 = prec == WN_BF16;
-    for (int i = 0; i < kMaxSeg; ++i) a.seg_nks[i] = g.seg_nks[i];
+    a.kgroups = g.k32 ? 4 : 2;                                   // k-groups of 8 channels per k-step
+    for (int i = 0; i < kMaxSeg; ++i) a.seg_nks[i] = g.seg_nks[i] / (g.k32 ? 2 : 1);
     for (int i = 0; i < g.nslab; ++i) {
         a.slab_woff[i] = g.slab_woff[i];
         a.slab_nseg[i] = g.slab_nseg[i];
@@ -288,11 +300,11 @@ int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params
         }
         a.set[0].bias0 = p->b_tanh; a.set[0].bias_rows = Co;
         a.set[1].bias0 = p->b_sigmoid; a.set[1].bias_rows = Co;
-        const int tiles = g.rows / 32, per_wave = tiles / 2;   // a wave owns MT consecutive tiles = MT/2 (a, g) pairs
+        const int tiles = g.rows / 32, per_wave = tiles / g.wave_rows();   // a wave owns per_wave consecutive tiles = per_wave/2 (a, g) pairs
         for (int sl = 0; sl < g.nslab; ++sl)
             for (int i = 0; i < tiles; ++i) {
                 const int wm = i / per_wave, tw = i % per_wave;            // wave row, tile inside the wave
-                const int ch0 = g.slab_row0[sl] + wm * 16 * g.MT + 32 * (tw / 2);
+                const int ch0 = g.slab_row0[sl] + wm * 16 * per_wave + 32 * (tw / 2);
                 a.tile[sl * tiles + i].set = tw & 1;
                 a.tile[sl * tiles + i].row0 = ch0 < Co ? ch0 : -1;
             }
@@ -363,7 +375,7 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
         a.gate_rows = Co;
         a.flag = overflow_flag;
         wn::ProfScopeShared prof(KC_HGATE, 2.0 * (2.0 * Co) * (double)(k * Ci) * BL, st);
-        WN_HIP(launch_hgemm(precision, g.MT, HEPI_GATE, a, st), "hgemm<gate>");
+        WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_GATE, a, st), "hgemm<gate>");
     }
     if (r_out) {
         const HPlan& g = bp.fr;
@@ -374,7 +386,7 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
         a.oscale = kResidualScale / kWeightScale;
         a.flag = overflow_flag;
         wn::ProfScopeShared prof(KC_HRES, 2.0 * Co * (double)(Co + Ci) * BL, st);
-        WN_HIP(launch_hgemm(precision, g.MT, HEPI_STORE, a, st), "hgemm<res>");
+        WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_STORE, a, st), "hgemm<res>");
     }
     if (skip_dense) {
         const HPlan& g = bp.fs;
@@ -382,7 +394,7 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
         set_hseg(a, 0, vz, 0, g.seg_nks[0]);
         a.out32 = skip_dense; a.out32_rows = Ms; a.out32_accum = skip_accumulate ? 1 : 0;
         wn::ProfScopeShared prof(KC_HSKIP, 2.0 * Ms * (double)Co * BL, st);
-        WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<skip>");
+        WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_F32, a, st), "hgemm<skip>");
     }
     return WN_OK;
 }
@@ -413,7 +425,7 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
         a.gate_rows = Co;
         a.flag = overflow_flag;
         wn::ProfScopeShared prof(KC_HDZ, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
-        WN_HIP(launch_hgemm(precision, g.MT, HEPI_DGATE, a, st), "hgemm<dz>");
+        WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_DGATE, a, st), "hgemm<dz>");
     }
     if (dx || dx_dense) {
         const HPlan& g = bp.kb;
@@ -429,10 +441,10 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
         wn::ProfScopeShared prof(KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
         if (dx) {
             a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
-            WN_HIP(launch_hgemm(precision, g.MT, HEPI_STORE, a, st), "hgemm<dx>");
+            WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_STORE, a, st), "hgemm<dx>");
         } else {
             a.out32 = dx_dense; a.out32_rows = Ci; a.out32_accum = 0; a.dyn_inv = dyn_inv_scale;
-            WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<dx dense>");
+            WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_F32, a, st), "hgemm<dx dense>");
         }
     }
     return WN_OK;
@@ -499,7 +511,7 @@ int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* pa
     for (int l = 0; l < s->nblocks; ++l) { set_hseg(a, l, view(z[l], s->channels[l], s->ld, P), 0, g.seg_nks[l]); ksum += s->channels[l]; }
     a.out32 = skip_dense; a.out32_rows = s->skip_rows; a.out32_accum = accumulate ? 1 : 0;
     wn::ProfScopeShared prof(KC_HSKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
-    WN_HIP(launch_hgemm(precision, g.MT, HEPI_F32, a, st), "hgemm<skipsum>");
+    WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_F32, a, st), "hgemm<skipsum>");
     return WN_OK;
 }
 
