@@ -237,13 +237,13 @@ SYMBOL_OF = {
 }
 SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm_kernel<\d+, \d+, 1,",
              "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"(?<![a-z])wgrad_kernel<",
-             "hlinear": r"hgemm_kernel<\d+, \d+, \w+, [03]>", "hgate": r"hgemm_kernel<\d+, \d+, \w+, 1>",
-             "hdgate": r"hgemm_kernel<\d+, \d+, \w+, 2>",
+             "hlinear": r"hgemm_kernel<\d+, \d+, \w+, [03]>", "hgate": r"hgemm8?_kernel<(?:\d+, )?\d+, \w+, 1>",
+             "hdgate": r"hgemm8?_kernel<(?:\d+, )?\d+, \w+, 2>",
              "hwgrad": r"hwgrad_kernel<"}
 SYMBOL_NAME = {"linear": "series_gemm_kernel<4, 4, 0, 3, 1>  [EPI_LINEAR: res, dx, skips_sum, conv launches]",
                "gate": "series_gemm_kernel<4, 4, 1, 3, 1>  [EPI_GATE]", "dgate": "series_gemm_kernel<4, 4, 2, 3, 1>  [EPI_DGATE: dz]",
                "wgrad": "wgrad_kernel<4>", "hlinear": "hgemm_kernel [EPI_LINEAR: res, dx, skips_sum]",
-               "hgate": "hgemm_kernel [EPI_GATE]", "hdgate": "hgemm_kernel [EPI_DGATE: dz]", "hwgrad": "hwgrad_kernel"}
+               "hgate": "hgemm8_kernel / hgemm_kernel [EPI_GATE]", "hdgate": "hgemm_kernel [EPI_DGATE: dz]", "hwgrad": "hwgrad_kernel"}
 
 
 def pmc_table(name):

@@ -113,8 +113,8 @@ def test_plain_half_modes_vs_oracle(precision):
 def test_full_tile_shapes_take_the_16x16x32_gemm(precision, c, dims, L, B):
     """rows a multiple of 256 (gate: channels a multiple of 128) and L a multiple of 128 select hgemm8_kernel in the f16x3 mode
     (256 x 128 tiles on v_mfma_f32_16x16x32, 32-channel k-steps, its own weight packing): all four epilogues against the
-    oracle.  The one-plane modes stay on hgemm_kernel for these shapes unless WN_HGEMM16=2 (test_one_plane_modes_on_the_
-    16x16x32_gemm runs them in a child process); WN_HGEMM16=0 keeps every shape on hgemm_kernel."""
+    oracle.  By default that is the gate and skips_sum GEMMs; test_every_gemm_and_mode_on_the_16x16x32_kernel runs the same
+    cases with WN_HGEMM16=2 (every GEMM, every mode) in a child process; WN_HGEMM16=0 keeps every shape on hgemm_kernel."""
     layers = [(c, c, 2, d) for d in dims]
     net = _cond_wavenet(c, layers, seed=c + L)
     g = torch.Generator().manual_seed(L + B)
@@ -128,16 +128,28 @@ def test_full_tile_shapes_take_the_16x16x32_gemm(precision, c, dims, L, B):
     assert O.rel_err(y_eval.cpu(), y_train.cpu()) < (1e-5 if precision == "f16x3" else 2e-2)
 
 
-def test_one_plane_modes_on_the_16x16x32_gemm():
-    """hgemm8_kernel's f16 / bf16 instantiations are not selected by default (slower there); force them in a child process"""
+def test_f16x3_two_skips_sum_groups_on_full_tiles():
+    """34 blocks = two long-K skips_sum launches (32 + 2 blocks), the second accumulating into the first's output, at a
+    shape that runs on hgemm8_kernel"""
+    c, L = 256, 128
+    layers = [(c, c, 2, 1 + (i % 3)) for i in range(34)]
+    net = _cond_wavenet(c, layers, seed=77)
+    g = torch.Generator().manual_seed(78)
+    x, cot = torch.randn(1, c, L, generator=g), torch.randn(1, c, L, generator=g)
+    _run(net, x, cot, layers, "f16x3", TOL)
+
+
+def test_every_gemm_and_mode_on_the_16x16x32_kernel():
+    """by default only the f16x3 gate and skips_sum GEMMs of full-tile shapes run on hgemm8_kernel (measured: the others gain
+    nothing or lose); WN_HGEMM16=2 in a child process puts every GEMM of every mode there: all epilogues, all three modes"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, WN_HGEMM16="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_half.py"), "-q", "-x", "-k",
-                        "full_tile and (f16-256 or bf16-256)"], env=env, cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+                        "full_tile or two_skips_sum"], env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
 
 
 def test_half_inference_matches_training_forward_and_is_deterministic():

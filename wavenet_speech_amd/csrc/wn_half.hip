@@ -955,17 +955,34 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-    } else {   // HEPI_F32: dense fp32 [B][rows][L], no accumulate (the plan keeps accumulating launches on hgemm_kernel)
+    } else {   // HEPI_F32: dense fp32 [B][rows][L]
         const float dsc = osc * (a.dyn_inv ? a.dyn_inv[0] : 1.0f);
         float* pbase = a.out32 + ((long long)b * a.out32_rows + sl.row0 + wm * 64 + 4 * rq) * a.L + t0 + wn * 64 + c16;
+        if (a.out32_accum) {   // the second skips_sum group of a > 32-block stack: all 64 reads in flight, then add and store
+            float old[4][4][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float* prow = pbase + (long long)(16 * m + q) * a.L;
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q];
-            }
+                    for (int n = 0; n < 4; ++n) old[m][q][n] = pbase[(long long)(16 * m + q) * a.L + 16 * n];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        pbase[(long long)(16 * m + q) * a.L + 16 * n] = acc[m][n][q] * dsc + bvec[m][q] + old[m][q][n];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float* prow = pbase + (long long)(16 * m + q) * a.L;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q];
+                }
+        }
     }
     if constexpr (!BF) {
         if (ovf && a.flag) atomicOr(a.flag, 1u);

@@ -86,14 +86,16 @@ struct HPlan {
     //            dz 0.370 -> 0.302, res 0.242 -> 0.229, dx 0.413 -> 0.403
     //   long_k = true  (skips_sum, K = 30 C): 256-row tiles, one workgroup per CU -- half the weight re-staging: 2.20 vs 2.53 ms
     //   hgemm8_kernel (k32): the 16x16x32 MFMA shape sustains a higher clock at the power limit; it takes FULL 256 x 128 tiles
-    //            only, so it is chosen when the row count is a multiple of 256 and L a multiple of 128 (cfg3, cfg5; WN_HGEMM16=0
-    //            turns it off for A/B runs).  Launches that accumulate into their output stay on hgemm_kernel.
-    void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool allow_k32 = false) {
-        static const bool k32_on = !(getenv("WN_HGEMM16") && atoi(getenv("WN_HGEMM16")) == 0);
-        // f16x3 only: measured at cfg3 245.7 vs 238.8 samples/s with it; in the one-plane modes (16 MFMAs per wave between
-        // barriers) it loses: cfg5 f16 89.1 vs 84.7 ms/step.  WN_HGEMM16=2 forces it on there too (tests).
-        static const bool k32_all = getenv("WN_HGEMM16") && atoi(getenv("WN_HGEMM16")) == 2;
-        k32 = (allow_k32 && k32_on && (planes_ == 2 || k32_all) && out_rows % 256 == 0 && length > 0 && length % 128 == 0) ? 1 : 0;
+    //            only (row count a multiple of 256, L a multiple of 128: cfg3, cfg5).  Measured against hgemm_kernel at cfg3,
+    //            f16x3, alternating runs on one device, on two devices: gate 0.407 vs 0.426 / 0.426 vs 0.425 ms, skips_sum
+    //            2.04 vs 2.14 / 2.20 vs 2.25, res 0.196 vs 0.197 / 0.202 vs 0.198, dz equal, dx 0.366 vs 0.361 / 0.395 vs
+    //            0.377; whole step 65.1 vs 67.0 / 68.0 vs 67.8 ms.  So `prefer` is set for the gate and skips_sum GEMMs only;
+    //            the one-plane modes lose with it (cfg5 f16 89.1 vs 84.7 ms/step: 16 MFMAs per wave between barriers).
+    //            WN_HGEMM16=0: never; =2: wherever the shape allows, every mode (tests).
+    void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool prefer_k32 = false) {
+        static const int knob = getenv("WN_HGEMM16") ? atoi(getenv("WN_HGEMM16")) : 1;
+        const bool fits = out_rows % 256 == 0 && length > 0 && length % 128 == 0;
+        k32 = (fits && (knob == 2 || (knob == 1 && prefer_k32 && planes_ == 2))) ? 1 : 0;
         MT = (k32 || (long_k && out_rows > 128)) ? 4 : 2;
         rows = 64 * MT;
         planes = planes_;
@@ -135,7 +137,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // FR: r rows contract [z ; x]
         HPlan& g = p.fr;
-        g.init(Co, P, false, s->length, true);
+        g.init(Co, P, false, s->length, false);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Co) / 16;
         g.seg_nks[1] = cp32(Ci) / 16;
@@ -143,14 +145,14 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // FS: skip rows contract [z]
         HPlan& g = p.fs;
-        g.init(Ms, P);
+        g.init(Ms, P);                                   // inference: accumulates per block -- always hgemm_kernel
         g.nseg = 1;
         g.seg_nks[0] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ms; r0 += g.rows) g.add_slab(1, r0);
     }
     {   // KA: dz rows (z channels) contract [dskip ; dr]
         HPlan& g = p.ka;
-        g.init(Co, P, false, s->length, true);
+        g.init(Co, P, false, s->length, false);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Ms) / 16;
         g.seg_nks[1] = cp32(Co) / 16;
@@ -158,7 +160,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KB: dx rows (input channels) contract [da_0; dg_0; ...; dr]
         HPlan& g = p.kb;
-        g.init(Ci, P, false, s->length, true);
+        g.init(Ci, P, false, s->length, false);
         g.nseg = 2 * k + 1;
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
@@ -465,7 +467,7 @@ int check_hskipsum(const wn_skipsum_shape* s, int prec) {
 }
 HPlan plan_hskipsum(const wn_skipsum_shape* s, int prec) {
     HPlan g;
-    g.init(s->skip_rows, hp_planes(prec), true);
+    g.init(s->skip_rows, hp_planes(prec), true, s->length, true);
     g.nseg = s->nblocks;
     for (int l = 0; l < s->nblocks; ++l) g.seg_nks[l] = cp32(s->channels[l]) / 16;
     for (int r0 = 0; r0 < s->skip_rows; r0 += g.rows) g.add_slab(s->nblocks, r0);
