@@ -299,6 +299,24 @@ int wn_prof_num_kernels(void);
 const char* wn_prof_kernel_name(int kernel_class);
 int wn_prof_get(int kernel_class, double* total_ms, long long* launches, double* flops);
 
+/* ---- stand-alone dilated conv in the half-precision modes: the half-series counterpart of wn_conv_* (CausalConv1d /
+ * NonCausalConv1d of modules/conv_ops.py:8-79 and the 1x1 Conv1d members of the output stacks), so that a model switched to a
+ * half mode runs ALL of its convolutions on the half kernels.  x and dy are half series (wn_hseries_load; x stored as
+ * x * input_scale, dy as dy * the call's gradient scale); y, dx, dweight, dbias are dense fp32.
+ *   forward          y[b][co][t]  = bias[co] + sum_j W[co][:][j] x[b][:][t + off_j]
+ *   backward_data    dx[b][ci][t] = sum_j W[:][ci][j]^T dy[b][:][t - off_j]            (* *dyn_inv_scale when given)
+ *   backward_weights dW[co][ci][j] = sum_{b,t} dy[b][co][t] x[b][ci][t + off_j] / input_scale;  db = row sums of dy   (same) */
+size_t wn_hconv_packed_bytes(const wn_conv_shape* s, int precision);
+int wn_hconv_pack(const wn_conv_shape* s, int precision, const float* weight /*[Co][Ci][k]*/, const float* bias /* may be NULL */,
+                  float input_scale, void* packed, wn_stream_t stream);
+int wn_hconv_forward(const wn_conv_shape* s, int precision, const void* packed, const void* x, float* y_dense, wn_stream_t stream);
+int wn_hconv_backward_data(const wn_conv_shape* s, int precision, const void* packed, const void* dy, float* dx_dense,
+                           const float* dyn_inv_scale /* DEVICE scalar, may be NULL */, wn_stream_t stream);
+size_t wn_hconv_wgrad_workspace_bytes(const wn_conv_shape* s, int precision);
+int wn_hconv_backward_weights(const wn_conv_shape* s, int precision, const void* x, const void* dy, float input_scale,
+                              float* dweight, float* dbias /* may be NULL */, const float* dyn_inv_scale /* may be NULL */,
+                              void* workspace, size_t workspace_bytes, wn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

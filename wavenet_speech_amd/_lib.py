@@ -91,6 +91,13 @@ SIGNATURES = {
     "wn_hblock_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, POINTER(BlockParams), c_float_p, c_void_p, c_size_t, c_void_p]),
+    "wn_hconv_packed_bytes": (c_size_t, [POINTER(ConvShape), c_int]),
+    "wn_hconv_pack": (c_int, [POINTER(ConvShape), c_int, c_float_p, c_float_p, c_float, c_void_p, c_void_p]),
+    "wn_hconv_forward": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_float_p, c_void_p]),
+    "wn_hconv_backward_data": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_float_p, c_float_p, c_void_p]),
+    "wn_hconv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvShape), c_int]),
+    "wn_hconv_backward_weights": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_float, c_float_p, c_float_p, c_float_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "wn_embed_forward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wn_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "wn_embed_backward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,

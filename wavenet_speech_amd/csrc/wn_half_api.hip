@@ -642,3 +642,146 @@ int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const voi
     return run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, dyn_inv_scale, workspace, workspace_bytes, false,
                       nullptr, (hipStream_t)stream);
 }
+
+// ==========================================================================================================================
+// stand-alone dilated conv in the half-precision modes (the entry conv and the 1x1 convs of the output stacks, so that a
+// model in a half mode runs all of its convolutions on the half kernels): wn_hconv_*, the half-series counterpart of wn_conv_*
+// ==========================================================================================================================
+namespace {
+int check_hconv(const wn_conv_shape* s, int prec, int* off) {
+    if (!s) return WN_ERR_NULL;
+    if (!half_prec(prec)) return WN_ERR_UNSUPPORTED;
+    if (s->in_channels <= 0 || s->out_channels <= 0 || s->dilation <= 0 || s->kernel_width < 1) return WN_ERR_BAD_SHAPE;
+    if (s->kernel_width > WN_MAX_TAPS || s->in_channels > WN_MAX_CHANNELS || s->out_channels > WN_MAX_CHANNELS) return WN_ERR_UNSUPPORTED;
+    wn_tap_offsets(s->kernel_width, s->dilation, s->causal, off);
+    int mx = 0;
+    for (int j = 0; j < s->kernel_width; ++j) mx = std::max(mx, std::abs(off[j]));
+    return check_hlayout(s->batch, s->length, s->ld, s->halo, mx);
+}
+struct HConvPlan { HPlan f, kb; size_t off_f = 0, off_kb = 0, total = 0; };
+HConvPlan plan_hconv(const wn_conv_shape* s, int prec) {
+    HConvPlan p;
+    const int P = hp_planes(prec), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    p.f.init(Co, P);
+    p.f.nseg = k;
+    for (int j = 0; j < k; ++j) p.f.seg_nks[j] = cp32(Ci) / 16;
+    for (int r0 = 0; r0 < Co; r0 += p.f.rows) p.f.add_slab(k, r0);
+    p.kb.init(Ci, P);
+    p.kb.nseg = k;
+    for (int j = 0; j < k; ++j) p.kb.seg_nks[j] = cp32(Co) / 16;
+    for (int r0 = 0; r0 < Ci; r0 += p.kb.rows) p.kb.add_slab(k, r0);
+    p.off_f = 0;
+    p.off_kb = p.f.bytes();
+    p.total = p.off_kb + p.kb.bytes();
+    return p;
+}
+}  // namespace
+
+size_t wn_hconv_packed_bytes(const wn_conv_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hconv(s, precision, off) != WN_OK) return 0;
+    return plan_hconv(s, precision).total;
+}
+
+int wn_hconv_pack(const wn_conv_shape* s, int precision, const float* weight, const float* bias, float input_scale, void* packed,
+                  wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!weight || !packed) return WN_ERR_NULL;
+    if (!(input_scale > 0.0f)) return WN_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const HConvPlan cp = plan_hconv(s, precision);
+    const int Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
+    HPackArgs a;
+    {   // forward: rows = output channel, taps of x (stored as x * input_scale)
+        fill_hpack(a, cp.f, packed, cp.off_f, precision);
+        for (int j = 0; j < k; ++j) a.set[0].seg[j] = hsrc(weight + j, Co, Ci, Ci * k, k, kWeightScale / input_scale);
+        a.set[0].bias0 = bias; a.set[0].bias_rows = bias ? Co : 0;
+        plain_tiles(a, cp.f, Co);
+        WN_HIP(launch_hpack(a, st), "hpack(conv)");
+    }
+    {   // backward data: rows = input channel, taps of dy
+        fill_hpack(a, cp.kb, packed, cp.off_kb, precision);
+        for (int j = 0; j < k; ++j) a.set[0].seg[j] = hsrc(weight + j, Ci, Co, k, Ci * k, kWeightScale);
+        plain_tiles(a, cp.kb, Ci);
+        a.bias = nullptr;
+        WN_HIP(launch_hpack(a, st), "hpack(conv dx)");
+    }
+    return WN_OK;
+}
+
+int wn_hconv_forward(const wn_conv_shape* s, int precision, const void* packed, const void* x, float* y_dense,
+                     wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !x || !y_dense) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HConvPlan cp = plan_hconv(s, precision);
+    const int P = hp_planes(precision), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    HGemmArgs a;
+    fill_hgemm(a, cp.f, packed, cp.off_f, s->batch, s->length, s->ld, s->halo);
+    const HView vx = view(x, Ci, s->ld, P);
+    for (int j = 0; j < k; ++j) set_hseg(a, j, vx, off[j], cp.f.seg_nks[j]);
+    a.out32 = y_dense; a.out32_rows = Co; a.out32_accum = 0;
+    wn::ProfScopeShared prof(KC_CONV_FWD, 2.0 * Co * (double)(k * Ci) * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, cp.f.kernel(), HEPI_F32, a, st), "hgemm<conv>");
+    return WN_OK;
+}
+
+int wn_hconv_backward_data(const wn_conv_shape* s, int precision, const void* packed, const void* dy, float* dx_dense,
+                           const float* dyn_inv_scale, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !dy || !dx_dense) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HConvPlan cp = plan_hconv(s, precision);
+    const int P = hp_planes(precision), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    HGemmArgs a;
+    fill_hgemm(a, cp.kb, packed, cp.off_kb, s->batch, s->length, s->ld, s->halo);
+    a.bias = nullptr;
+    const HView vdy = view(dy, Co, s->ld, P);
+    for (int j = 0; j < k; ++j) set_hseg(a, j, vdy, -off[j], cp.kb.seg_nks[j]);
+    a.out32 = dx_dense; a.out32_rows = Ci; a.out32_accum = 0; a.dyn_inv = dyn_inv_scale;
+    wn::ProfScopeShared prof(KC_CONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, cp.kb.kernel(), HEPI_F32, a, st), "hgemm<conv dx>");
+    return WN_OK;
+}
+
+namespace {
+std::vector<HPairSpec> hconv_pairs(const wn_conv_shape* s, const int* off, const void* x, const void* dy, float* dw, float* db,
+                                   float input_scale) {
+    std::vector<HPairSpec> ps;
+    const int Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    for (int j = 0; j < k; ++j)
+        ps.push_back({dy, Co, x, Ci, off[j], (j == 0 && db) ? 1 : 0, 1.0f / input_scale, dw ? dw + j : nullptr, Ci * k, k,
+                      (j == 0) ? db : nullptr, nullptr});
+    return ps;
+}
+}  // namespace
+
+size_t wn_hconv_wgrad_workspace_bytes(const wn_conv_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hconv(s, precision, off) != WN_OK) return 0;
+    static float dummy = 0;
+    size_t need = 0;
+    std::vector<HPairSpec> ps = hconv_pairs(s, off, &dummy, &dummy, &dummy, &dummy, 1.0f);
+    run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, nullptr, nullptr, 0, true, &need, nullptr);
+    return need;
+}
+
+int wn_hconv_backward_weights(const wn_conv_shape* s, int precision, const void* x, const void* dy, float input_scale,
+                              float* dweight, float* dbias, const float* dyn_inv_scale, void* workspace, size_t workspace_bytes,
+                              wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!x || !dy || !dweight) return WN_ERR_NULL;
+    if (!(input_scale > 0.0f)) return WN_ERR_BAD_SHAPE;
+    std::vector<HPairSpec> ps = hconv_pairs(s, off, x, dy, dweight, dbias, input_scale);
+    return run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, dyn_inv_scale, workspace, workspace_bytes, false, nullptr,
+                      (hipStream_t)stream);
+}

@@ -396,7 +396,10 @@ class _DilatedConvFn(torch.autograd.Function):
         return dx0, dw, db, None, None, None
 
 
-def dilated_conv(x, weight, bias, dilation=1, causal=True):
+def dilated_conv(x, weight, bias, dilation=1, causal=True, precision="f32"):
+    if precision != "f32":
+        from . import functional_half
+        return functional_half.conv(x, weight, bias, dilation, causal, precision)
     return _DilatedConvFn.apply(x, weight, bias, int(dilation), bool(causal), torch.is_grad_enabled())
 
 

@@ -215,3 +215,85 @@ def residual_stack(x, specs, flat_params, precision, pack_cache=None):
     if precision not in ("f16x3", "f16", "bf16"):
         raise ValueError("unknown precision %r" % (precision,))
     return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, *flat_params)
+
+
+class _HalfConvFn(torch.autograd.Function):
+    """CausalConv1d / NonCausalConv1d / 1x1 Conv1d (modules/conv_ops.py:39-44, 73-79) on the half-precision kernels
+    (wn_hconv_*): dense fp32 in and out like functional.dilated_conv, half series and MFMAs inside.  Used by the conv
+    modules and the output stacks of a model that set_precision switched to a half mode."""
+
+    @staticmethod
+    @_on_device_of_first_tensor
+    def forward(ctx, x, weight, bias, dilation, causal, mode, grad_enabled):
+        lib = _lib.load()
+        _require_device(x, "input")
+        _require_device(weight, "weight")
+        _flags.WATCH.poll()
+        B, Ci, L = x.shape
+        Co, Ci_w, k = weight.shape
+        if Ci_w != Ci:
+            raise RuntimeError("wavenet_speech_amd: input has %d channels, conv expects %d" % (Ci, Ci_w))
+        dev = x.device
+        reach = max(abs(o) for o in _lib.tap_offsets(k, dilation, causal))
+        layout = HalfLayout(L, reach)
+        shape = _lib.ConvShape(B, L, Ci, Co, k, int(dilation), int(bool(causal)), layout.ld, layout.halo)
+        training = bool(grad_enabled) and any(ctx.needs_input_grad)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
+        rs = float(lib.wn_hseries_residual_scale())           # inputs are stored as x / 16 like the residual stream
+        nbytes = lib.wn_hconv_packed_bytes(ctypes.byref(shape), mode.code)
+        if nbytes == 0:
+            _lib.check(-1 if k <= _lib.MAX_TAPS else -2, "wn_hconv_packed_bytes")
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        _lib.check(lib.wn_hconv_pack(ctypes.byref(shape), mode.code, _p(w), _p(b), ctypes.c_float(rs), _p(packed), _stream()),
+                   "wn_hconv_pack")
+        xin = _hlease(mode, B, Ci, layout, dev)
+        _load(lib, mode, x.detach().contiguous(), xin, layout, rs, None, flag)
+        y = torch.empty(B, Co, L, dtype=torch.float32, device=dev)
+        _lib.check(lib.wn_hconv_forward(ctypes.byref(shape), mode.code, _p(packed), _p(xin), _p(y), _stream()), "wn_hconv_forward")
+        _flags.WATCH.note(flag, _OVERFLOW_MSG % "input of a conv", at_once=not training)
+        if training:
+            ctx.saved = (xin, packed, shape)
+        ctx.layout, ctx.dims, ctx.has_bias, ctx.mode, ctx.rs = layout, (B, Ci, Co, k), bias is not None, mode, rs
+        return y
+
+    @staticmethod
+    @once_differentiable
+    @_on_device_of_first_tensor
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        _flags.WATCH.poll()
+        xin, packed, shape = ctx.saved
+        layout, mode = ctx.layout, ctx.mode
+        B, Ci, Co, k = ctx.dims
+        dev = d_y.device
+        d_y = d_y.contiguous()
+        flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
+        amax = d_y.abs().amax().clamp_min(1e-30)
+        dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
+        dyn_inv = (1.0 / dyn).contiguous()
+        dy = _hlease(mode, B, Co, layout, dev)
+        _load(lib, mode, d_y, dy, layout, 1.0, dyn, flag)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, Ci, layout.length, dtype=torch.float32, device=dev)
+            _lib.check(lib.wn_hconv_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dy), _p(dx), _p(dyn_inv), _stream()),
+                       "wn_hconv_backward_data")
+        dw = torch.empty(Co, Ci, k, dtype=torch.float32, device=dev)
+        db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws_bytes = lib.wn_hconv_wgrad_workspace_bytes(ctypes.byref(shape), mode.code)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        _lib.check(lib.wn_hconv_backward_weights(ctypes.byref(shape), mode.code, _p(xin), _p(dy), ctypes.c_float(ctx.rs), _p(dw),
+                                                 _p(db), _p(dyn_inv), _p(ws), ws_bytes, _stream()), "wn_hconv_backward_weights")
+        _flags.WATCH.note(flag, _OVERFLOW_MSG % "gradient of a conv", at_once=False)
+        ctx.saved = None
+        return dx, dw, db, None, None, None, None
+
+
+def conv(x, weight, bias, dilation, causal, precision):
+    """functional.dilated_conv in a half-precision mode ("f16x3" / "f16" / "bf16")"""
+    if precision not in ("f16x3", "f16", "bf16"):
+        raise ValueError("unknown precision %r" % (precision,))
+    return _HalfConvFn.apply(x, weight, bias, int(dilation), bool(causal), _Mode(precision), torch.is_grad_enabled())
+

@@ -44,9 +44,10 @@ class _DilatedConv1d(nn.Module):
         self.conv1d = nn.Conv1d(in_channels, out_channels, kernel_width, stride=1, padding=self.padding,
                                 dilation=dilation)
         self.receptive_field = kernel_width + (dilation - 1) * (kernel_width - 1)
+        self.precision = "f32"   # arithmetic mode, switched together with the model's residual stack by block.set_precision
 
     def forward(self, seq):
-        return HF.dilated_conv(seq, self.conv1d.weight, self.conv1d.bias, self.dilation, self.causal)
+        return HF.dilated_conv(seq, self.conv1d.weight, self.conv1d.bias, self.dilation, self.causal, self.precision)
 
 
 class CausalConv1d(_DilatedConv1d):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from .. import functional as HF
 
 
-def conv1d_same_as_torch(conv, x):
+def conv1d_same_as_torch(conv, x, precision="f32"):
     """nn.Conv1d(stride 1, dilation 1, padding p in {0, k-1}) through HF.dilated_conv.
     padding k-1 on both sides (RawCTCNet.feature_layer[0]) lengthens the series to L+k-1:
     y[t] = sum_j W[j] x[t + j - (k-1)], i.e. the causal conv of x followed by k-1 trailing zeros."""
@@ -26,10 +26,11 @@ def conv1d_same_as_torch(conv, x):
         x = F.pad(x, (0, k - 1))
     elif k > 1:
         raise RuntimeError("wavenet_speech_amd: unpadded k>1 Conv1d is not part of the path")
-    return HF.dilated_conv(x, conv.weight, conv.bias, 1, True)
+    return HF.dilated_conv(x, conv.weight, conv.bias, 1, True, precision)
 
 
-def run_sequential(seq, x):
+def run_sequential(seq, x, precision="f32"):
+    """`precision`: the arithmetic mode of the model's residual stack (block.set_precision): its Conv1d members follow it"""
     for mod in seq:
-        x = conv1d_same_as_torch(mod, x) if isinstance(mod, nn.Conv1d) else mod(x)
+        x = conv1d_same_as_torch(mod, x, precision) if isinstance(mod, nn.Conv1d) else mod(x)
     return x

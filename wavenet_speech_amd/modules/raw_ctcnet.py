@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, StackState, run_stack
+from .block import ResidualBlock, StackState, run_stack, pointwise_precision
 from .pointwise import run_sequential
 
 
@@ -56,13 +56,13 @@ class RawCTCNet(nn.Module):
                     noisy_zero(p)
 
     def forward(self, seq):
-        out = run_sequential(self.feature_layer, seq)
+        out = run_sequential(self.feature_layer, seq, pointwise_precision(self.stack_state.precision))
         if self.positions:
             steps = torch.arange(0., out.size(2), device=seq.device).view(1, 1, -1)
-            out = out + run_sequential(self.positions_conv1x1, steps)
+            out = out + run_sequential(self.positions_conv1x1, steps, pointwise_precision(self.stack_state.precision))
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
                               [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
-        logit_seq = run_sequential(self.output_block, skips_sum)
+        logit_seq = run_sequential(self.output_block, skips_sum, pointwise_precision(self.stack_state.precision))
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)
