@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define WN_VERSION 200 /* 0.2.0 */
+#define WN_VERSION 201 /* 0.2.1 */
 
 typedef void* wn_stream_t; /* hipStream_t */
 
@@ -267,10 +267,11 @@ int wn_hseries_load(int precision, const float* dense, void* series, int batch, 
 
 size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision);
 int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream);
-/* x, r_out (nullable), ta, sg (nullable together), z: half series.  skip_dense (nullable): dense fp32 [B][Ms][L] that
- * receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference. */
+/* x, r_out (nullable), sg (nullable: inference), z: half series.  z = tanh(a) sigmoid(g) and sg = sigmoid(g) are what the
+ * backward pass needs (the tanh is recovered as z / sg: one tensor less to write and to keep).  skip_dense (nullable): dense
+ * fp32 [B][Ms][L] that receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference. */
 int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
-                      float* skip_dense, int skip_accumulate, void* ta, void* sg, void* z, unsigned* overflow_flag,
+                      float* skip_dense, int skip_accumulate, void* sg, void* z, unsigned* overflow_flag,
                       wn_stream_t stream);
 size_t wn_hskipsum_packed_bytes(const wn_skipsum_shape* s, int precision);
 int wn_hskipsum_pack(const wn_skipsum_shape* s, int precision, const float* const* w_skip, const float* bias_total,
@@ -278,10 +279,11 @@ int wn_hskipsum_pack(const wn_skipsum_shape* s, int precision, const float* cons
 /* z[l]: half series of every block; skip_dense: dense fp32 [B][Ms][L] */
 int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* packed, const void* const* z,
                         float* skip_dense, int accumulate, wn_stream_t stream);
-/* dr (nullable), dskip, ta, sg, da, dg: half series (gradients carry the scale s).  The input gradient goes either to the
- * half series dx (scaled by s, the next block's dr) or to dense fp32 dx_dense [B][Ci][L] multiplied by *dyn_inv_scale. */
+/* dr (nullable), dskip, z, sg (the forward pass's), da, dg: half series (gradients carry the scale s).  The input gradient goes
+ * either to the half series dx (scaled by s, the next block's dr) or to dense fp32 dx_dense [B][Ci][L] multiplied by
+ * *dyn_inv_scale. */
 int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
-                            const void* ta, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                            const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                             const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream);
 size_t wn_hblock_wgrad_workspace_bytes(const wn_block_shape* s, int precision);
 /* gradients in PyTorch layouts, fp32, multiplied by *dyn_inv_scale (and by the residual-stream scale where x is an operand) */

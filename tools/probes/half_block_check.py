@@ -36,9 +36,9 @@ nbytes = lib.wn_hblock_packed_bytes(ctypes.byref(shape), mode.code)
 packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
 ps = HF._params_struct(Pd)
 _lib.check(lib.wn_hblock_pack(ctypes.byref(shape), mode.code, ctypes.byref(ps), HF._p(packed), HF._stream()), "pack")
-r, ta, sg, z = (FH._hlease(mode, B, C, layout, dev) for _ in range(4))
+r, sg, z = (FH._hlease(mode, B, C, layout, dev) for _ in range(3))
 S = torch.empty(B, C, L, device=dev)
-_lib.check(lib.wn_hblock_forward(ctypes.byref(shape), mode.code, HF._p(packed), HF._p(xin), HF._p(r), HF._p(S), 0, HF._p(ta), HF._p(sg),
+_lib.check(lib.wn_hblock_forward(ctypes.byref(shape), mode.code, HF._p(packed), HF._p(xin), HF._p(r), HF._p(S), 0, HF._p(sg),
                                  HF._p(z), HF._p(flag), HF._stream()), "fwd")
 torch.cuda.synchronize()
 xd = x.double()
@@ -56,11 +56,11 @@ z0 = ta0 * sg0
 r0 = torch.einsum("oc,bct->bot", Wd[4], z0) + Wd[5].view(1, -1, 1) + torch.einsum("oc,bct->bot", Wd[8], xd) + Wd[9].view(1, -1, 1)
 s0 = torch.einsum("oc,bct->bot", Wd[6], z0) + Wd[7].view(1, -1, 1)
 def rel(got, ref): return float((got - ref).abs().max() / ref.abs().max())
-print("ta", rel(readback(ta, 1), ta0), "sg", rel(readback(sg, 1), sg0), "z", rel(readback(z, 1), z0))
+print("sg", rel(readback(sg, 1), sg0), "z", rel(readback(z, 1), z0), "tanh recovered as z / sg", rel(readback(z, 1) / readback(sg, 1), ta0))
 print("r ", rel(readback(r, rs), r0), "skip", rel(S.double().cpu(), s0), "flag", int(flag.item()))
 # atanh-level check of the pre-activation: invert the gate where it is well conditioned
 am = a.abs() < 1.0
-print("a (via atanh, |a|<1)", float(((torch.atanh(readback(ta, 1).clamp(-0.999999, 0.999999)) - a)[am]).abs().max()))
+print("a (via atanh of z / sg, |a|<1)", float(((torch.atanh((readback(z, 1) / readback(sg, 1)).clamp(-0.999999, 0.999999)) - a)[am]).abs().max()))
 # ---- where is z wrong? ----
 zt = z.t.float().view(B, mode.planes, FH._cp32(C) // 8, layout.ld, 8)
 def plane(p):

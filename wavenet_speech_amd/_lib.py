@@ -82,7 +82,7 @@ SIGNATURES = {
     "wn_hblock_packed_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_pack": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p]),
     "wn_hblock_forward": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p]),
     "wn_hskipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape), c_int]),
     "wn_hskipsum_pack": (c_int, [POINTER(SkipSumShape), c_int, POINTER(c_void_p), c_float_p, c_void_p, c_void_p]),
     "wn_hskipsum_forward": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
@@ -138,7 +138,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.wn_version() < 200:
+    if lib.wn_version() < 201:
         raise RuntimeError("libwavenet_amd.so too old")
     _lib = lib
     return lib

@@ -57,7 +57,7 @@ struct HGemmArgs {
     HSeg seg[kMaxSeg];
     HSlab slab[kHMaxSlab];
     HDst dst[2];            // HEPI_STORE: dst[slab.dst]
-    HDst ta, sg, z;         // HEPI_GATE out (ta.base may be nullptr: inference) / HEPI_DGATE in
+    HDst sg, z;             // HEPI_GATE out (sg.base may be nullptr: inference) / HEPI_DGATE in (tanh = z / sigmoid)
     HDst da, dg;            // HEPI_DGATE out
     float* out32;           // HEPI_F32: dense [B][out32_rows][L] fp32
     const float* dyn_inv;   // HEPI_F32: optional device scalar multiplied into the result (1 / dynamic gradient scale)

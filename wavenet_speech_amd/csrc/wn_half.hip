@@ -114,6 +114,16 @@ __device__ __forceinline__ float h_tanh(float x) {   // same formulation as the 
     return __builtin_copysignf(ax < 0.125f ? small : big, x);
 }
 
+// backward of the gate from what the forward pass keeps: z = tanh(a) sigmoid(g) and s = sigmoid(g).  The tanh is not stored
+// (one tensor less to write in the forward gate launch and to keep until backward): t = z / s.
+//     da = dz s (1 - t^2) = dz (s - z t)         dg = dz t s (1 - s) = dz z (1 - s)
+// s = 0 (sigmoid underflow) has z = 0 and both gradients 0.  An error in the recovered t enters da multiplied by z <= s.
+__device__ __forceinline__ void dgate(float dz, float z, float s, float& da, float& dg) {
+    const float t = s > 0.0f ? z / s : 0.0f;
+    da = dz * (s - z * t);
+    dg = dz * z * (1.0f - s);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dense fp32 [B][C][L]  ->  half series
 // ---------------------------------------------------------------------------------------------------------------
@@ -475,8 +485,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
             int bq = b;
             if (a.dbg & 4) { bq = 0; col = ((long long)a.halo + (t0 & 1023) + wn * 128 + r) * 16 + 8 * h; }   // measurement: every tile stores into the first 1024 columns (L2-resident)
             char* zb = a.z.base + (long long)bq * a.z.ustride + col;
-            const bool keep = a.ta.base != nullptr;            // training: tanh and sigmoid are kept for the backward pass
-            char* tb = keep ? a.ta.base + (long long)bq * a.ta.ustride + col : zb;
+            const bool keep = a.sg.base != nullptr;            // training: the sigmoid is kept for the backward pass (tanh = z / sigmoid)
             char* sb = keep ? a.sg.base + (long long)bq * a.sg.ustride + col : zb;
 #pragma unroll
             for (int j = 0; j < MT / 2; ++j)
@@ -494,10 +503,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                         }
                         const long long on = o + n * 512;
                         store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
-                        if (keep) {     // wave-uniform; no load is pending, so the join costs no wait
-                            store4<P, BF, false>(tb + on, a.ta.pstride, vt, ovf);
-                            store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
-                        }
+                        if (keep) store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);   // wave-uniform; no load is pending
                     }
                 }
             if constexpr (!BF) {
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
         if (full_cols && sl.row0 + ROWS <= a.da.cp) {
             typedef typename HT<BF>::v4 V4;
             const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
-            const char* tab = a.ta.base + (long long)b * a.ta.ustride + col;
+            const char* tab = a.z.base + (long long)b * a.z.ustride + col;          // z = tanh * sigmoid (the tanh itself is not stored)
             const char* sgb = a.sg.base + (long long)b * a.sg.ustride + col;
             char* dab = a.da.base + (long long)b * a.da.ustride + col;
             char* dgb = a.dg.base + (long long)b * a.dg.ustride + col;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 512 + p * a.ta.pstride);
+                        ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 512 + p * a.z.pstride);
                         fs[n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 512 + p * a.sg.pstride);
                     }
             };
@@ -537,11 +543,10 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                     float va[4], vg[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float t_ = (float)rt[g & 1][n][0][q], s_ = (float)rs[g & 1][n][0][q];
-                        if constexpr (P == 2) { t_ += (float)rt[g & 1][n][1][q]; s_ += (float)rs[g & 1][n][1][q]; }
+                        float z_ = (float)rt[g & 1][n][0][q], s_ = (float)rs[g & 1][n][0][q];
+                        if constexpr (P == 2) { z_ += (float)rt[g & 1][n][1][q]; s_ += (float)rs[g & 1][n][1][q]; }
                         const float dz = acc[m][n][4 * i + q] * osc;
-                        va[q] = dz * s_ * (1.0f - t_ * t_);
-                        vg[q] = dz * t_ * s_ * (1.0f - s_);
+                        dgate(dz, z_, s_, va[q], vg[q]);
                     }
                     store4<P, BF>(dab + o + n * 512, a.da.pstride, va, ovf);
                     store4<P, BF>(dgb + o + n * 512, a.dg.pstride, vg, ovf);
@@ -624,10 +629,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                             }
                             const long long on = o + n * 512;
                             store4<P, BF, false>(a.z.base + (long long)b * a.z.ustride + on, a.z.pstride, vz, ovf);
-                            if (a.ta.base) {
-                                store4<P, BF, false>(a.ta.base + (long long)b * a.ta.ustride + on, a.ta.pstride, vt, ovf);
-                                store4<P, BF, false>(a.sg.base + (long long)b * a.sg.ustride + on, a.sg.pstride, vs, ovf);
-                            }
+                            if (a.sg.base) store4<P, BF, false>(a.sg.base + (long long)b * a.sg.ustride + on, a.sg.pstride, vs, ovf);
                         }
                     }
                 }
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                     float ta_[4][4], sg_[4][4];
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {     // all eight (sixteen with lo planes) loads of the row group in flight together
-                        load4<P, BF>(a.ta.base + (long long)b * a.ta.ustride + o + n * 512, a.ta.pstride, ta_[n]);
+                        load4<P, BF>(a.z.base + (long long)b * a.z.ustride + o + n * 512, a.z.pstride, ta_[n]);   // z, not tanh
                         load4<P, BF>(a.sg.base + (long long)b * a.sg.ustride + o + n * 512, a.sg.pstride, sg_[n]);
                     }
 #pragma unroll
@@ -654,9 +656,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float dz = acc[m][n][4 * i + q] * osc;
-                                const float t_ = ta_[n][q], s_ = sg_[n][q];
-                                va[q] = dz * s_ * (1.0f - t_ * t_);
-                                vg[q] = dz * t_ * s_ * (1.0f - s_);
+                                dgate(dz, ta_[n][q], sg_[n][q], va[q], vg[q]);
                             }
                             store4<P, BF>(a.da.base + (long long)b * a.da.ustride + o + n * 512, a.da.pstride, va, ovf);
                             store4<P, BF>(a.dg.base + (long long)b * a.dg.ustride + o + n * 512, a.dg.pstride, vg, ovf);
@@ -894,8 +894,7 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
         // tile rows 0..31 of a wave are a, 32..63 are g of the same 32 channels: pairs (m, m + 2)
         const long long o0 = col + (long long)(((sl.row0 + wm * 32) >> 3) + (rq >> 1)) * ld * 16;
         char* zb = a.z.base + (long long)b * a.z.ustride + o0;
-        const bool keep = a.ta.base != nullptr;
-        char* tb = keep ? a.ta.base + (long long)b * a.ta.ustride + o0 : zb;
+        const bool keep = a.sg.base != nullptr;
         char* sb = keep ? a.sg.base + (long long)b * a.sg.ustride + o0 : zb;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -910,15 +909,12 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
                 }
                 const long long on = (long long)(2 * m) * ld * 16 + n * 256;
                 store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
-                if (keep) {
-                    store4<P, BF, false>(tb + on, a.ta.pstride, vt, ovf);
-                    store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
-                }
+                if (keep) store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
             }
     } else if constexpr (EPI == HEPI_DGATE) {
         typedef typename HT<BF>::v4 V4;
         const long long o0 = col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
-        const char* tab = a.ta.base + (long long)b * a.ta.ustride + o0;
+        const char* tab = a.z.base + (long long)b * a.z.ustride + o0;            // z = tanh * sigmoid (the tanh itself is not stored)
         const char* sgb = a.sg.base + (long long)b * a.sg.ustride + o0;
         char* dab = a.da.base + (long long)b * a.da.ustride + o0;
         char* dgb = a.dg.base + (long long)b * a.dg.ustride + o0;
@@ -929,7 +925,7 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 256 + p * a.ta.pstride);
+                    ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 256 + p * a.z.pstride);
                     fs[n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 256 + p * a.sg.pstride);
                 }
         };
@@ -944,11 +940,10 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
                 float va[4], vg[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float t_ = (float)rt[m & 1][n][0][q], s_ = (float)rs[m & 1][n][0][q];
-                    if constexpr (P == 2) { t_ += (float)rt[m & 1][n][1][q]; s_ += (float)rs[m & 1][n][1][q]; }
+                    float z_ = (float)rt[m & 1][n][0][q], s_ = (float)rs[m & 1][n][0][q];
+                    if constexpr (P == 2) { z_ += (float)rt[m & 1][n][1][q]; s_ += (float)rs[m & 1][n][1][q]; }
                     const float dz = acc[m][n][q] * osc;
-                    va[q] = dz * s_ * (1.0f - t_ * t_);
-                    vg[q] = dz * t_ * s_ * (1.0f - s_);
+                    dgate(dz, z_, s_, va[q], vg[q]);
                 }
                 store4<P, BF>(dab + o + n * 256, a.da.pstride, va, ovf);
                 store4<P, BF>(dgb + o + n * 256, a.dg.pstride, vg, ovf);

@@ -4,7 +4,7 @@
 //
 // Scales (all exact powers of two, so they never cost a rounding):
 //   residual stream x / r      stored as  value * kResidualScale (1/16): fp16 then holds |r| up to 1.0e6
-//   ta, sg, z                  stored as is (|.| <= 1)
+//   sg, z                      stored as is (|.| <= 1); tanh is not stored: z / sg
 //   gradient series            stored as  value * s, s = a per-backward-call device scalar chosen by the host from max|d skips_sum|
 //   packed weights             256 * w / (scale of the segment's input), so an accumulator is 256 * true result
 #include <hip/hip_runtime.h>
@@ -354,13 +354,12 @@ int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params
 }
 
 int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
-                      float* skip_dense, int skip_accumulate, void* ta, void* sg, void* z, unsigned* overflow_flag,
+                      float* skip_dense, int skip_accumulate, void* sg, void* z, unsigned* overflow_flag,
                       wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
     if (!packed || !x || !z) return WN_ERR_NULL;
-    if ((ta == nullptr) != (sg == nullptr)) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const HBlockPlan bp = plan_hblock(s, precision);
     const int P = hp_planes(precision);
@@ -373,7 +372,7 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
         fill_hgemm(a, g, packed, bp.off_fa, s->batch, s->length, s->ld, s->halo);
         for (int j = 0; j < k; ++j) set_hseg(a, j, vx, off[j], g.seg_nks[j]);
         a.z = dst_of(vz);
-        if (ta) { a.ta = dst_of(view(ta, Co, s->ld, P)); a.sg = dst_of(view(sg, Co, s->ld, P)); }
+        if (sg) a.sg = dst_of(view(sg, Co, s->ld, P));
         a.gate_rows = Co;
         a.flag = overflow_flag;
         wn::ProfScopeShared prof(KC_HGATE, 2.0 * (2.0 * Co) * (double)(k * Ci) * BL, st);
@@ -402,12 +401,12 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
 }
 
 int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
-                            const void* ta, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                            const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                             const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
-    if (!packed || !dskip || !ta || !sg || !da || !dg) return WN_ERR_NULL;
+    if (!packed || !dskip || !z || !sg || !da || !dg) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const HBlockPlan bp = plan_hblock(s, precision);
     const int P = hp_planes(precision);
@@ -422,7 +421,7 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
         set_hseg(a, 0, view(dskip, Ms, s->ld, P), 0, g.seg_nks[0]);
         if (dr) set_hseg(a, 1, view(dr, Co, s->ld, P), 0, g.seg_nks[1]);
         for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = dr ? 2 : 1;
-        a.ta = dst_of(view(ta, Co, s->ld, P)); a.sg = dst_of(view(sg, Co, s->ld, P));
+        a.z = dst_of(view(z, Co, s->ld, P)); a.sg = dst_of(view(sg, Co, s->ld, P));
         a.da = dst_of(vda); a.dg = dst_of(vdg);
         a.gate_rows = Co;
         a.flag = overflow_flag;

@@ -123,17 +123,17 @@ class _HalfStackFn(torch.autograd.Function):
                     pack_cache.put(l, layout, B, packed)
             r = _hlease(mode, B, spec.co, layout, dev) if l + 1 < n else None
             if training:
-                ta, sg, z = (_hlease(mode, B, spec.co, layout, dev) for _ in range(3))
+                sg, z = (_hlease(mode, B, spec.co, layout, dev) for _ in range(2))   # kept for backward; tanh = z / sg
             else:
-                ta = sg = None
+                sg = None
                 if zbuf is None or zbuf.channels != spec.co:
                     zbuf = _hlease(mode, B, spec.co, layout, dev)
                 z = zbuf
             _lib.check(lib.wn_hblock_forward(ctypes.byref(shape), mode.code, _p(packed), _p(cur), _p(r),
-                                             None if training else _p(S), 0 if l == 0 else 1, _p(ta), _p(sg), _p(z),
+                                             None if training else _p(S), 0 if l == 0 else 1, _p(sg), _p(z),
                                              _p(flag), _stream()), "wn_hblock_forward")
             if training:
-                saved.append((cur, ta, sg, z, packed, shape))
+                saved.append((cur, sg, z, packed, shape))
                 skip_w.append(params[6])
                 skip_b.append(params[7])
             cur = r
@@ -151,7 +151,7 @@ class _HalfStackFn(torch.autograd.Function):
                     _lib.check(-1, "wn_hskipsum_packed_bytes")
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 wptrs = (ctypes.c_void_p * m)(*[skip_w[l].data_ptr() for l in idx])
-                zptrs = (ctypes.c_void_p * m)(*[saved[l][3].ptr for l in idx])
+                zptrs = (ctypes.c_void_p * m)(*[saved[l][2].ptr for l in idx])
                 _lib.check(lib.wn_hskipsum_pack(ctypes.byref(shape), mode.code, wptrs, _p(bias_total) if g0 == 0 else None,
                                                 _p(packed), _stream()), "wn_hskipsum_pack")
                 _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
@@ -182,14 +182,14 @@ class _HalfStackFn(torch.autograd.Function):
         grads_flat = [None] * (len(specs) * PARAMS_PER_BLOCK)
         for l in range(len(specs) - 1, -1, -1):
             spec = specs[l]
-            x, ta, sg, z, packed, shape = ctx.saved[l]
+            x, sg, z, packed, shape = ctx.saved[l]
             da, dg = _hlease(mode, B, spec.co, layout, dev), _hlease(mode, B, spec.co, layout, dev)
             dx = dxd = None
             if l > 0:
                 dx = _hlease(mode, B, spec.ci, layout, dev)
             elif ctx.needs_input_grad[0]:
                 dxd = dx0 = torch.empty(B, spec.ci, layout.length, dtype=torch.float32, device=dev)
-            _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(ta), _p(sg),
+            _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
                                                    _p(da), _p(dg), _p(dx), _p(dxd), _p(dyn_inv), _p(flag), _stream()),
                        "wn_hblock_backward_data")
             k = spec.k
