@@ -110,11 +110,12 @@ int wn_block_pack(const wn_block_shape* s, const wn_block_params* p, void* packe
  *   skip = W_skip z + b_skip                                         -> skip  (skip_accumulate=0)
  *   skip += W_skip z + b_skip   (the stack's running skips_sum)       -> skip  (skip_accumulate=1)
  *   skip == NULL: the skip product is left to wn_skipsum_forward (below)
- *   ta, sg, z are saved for the backward pass (each may be NULL for inference, all-or-none).
- * x: [B][Ci8][ld]; r_out, ta, sg, z: [B][Co8][ld]; skip: [B][Ms8][ld]. */
+ *   z (always written) and sg (may be NULL for inference) are what the backward pass needs: the tanh is recovered as z / sg
+ *   there, which saves one tensor per block in the forward launch's stores and in the state held until backward.
+ * x: [B][Ci8][ld]; r_out, sg, z: [B][Co8][ld]; skip: [B][Ms8][ld]. */
 int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x,
                      float* r_out, float* skip, int skip_accumulate,
-                     float* ta, float* sg, float* z, wn_stream_t stream);
+                     float* sg, float* z, wn_stream_t stream);
 
 /* ---- skips_sum of a whole stack as ONE long-K product (training, where every block's z is kept anyway) ----
  *   skip (+)= sum_l W_skip_l z_l + bias_total        == the sum over l of modules/wavenet.py:100
@@ -134,12 +135,12 @@ int wn_skipsum_forward(const wn_skipsum_shape* s, const void* packed, const floa
                        int accumulate, wn_stream_t stream);
 
 /* ---- backward (data): what autograd computes through modules/block.py:54-82 ----------------
- *   dz = W_res^T dr + W_skip^T dskip ;  da = dz*sg*(1-ta^2) ;  dg = dz*ta*sg*(1-sg)     -> da, dg
+ *   dz = W_res^T dr + W_skip^T dskip ;  da = dz*sg*(1-ta^2) ;  dg = dz*ta*sg*(1-sg), ta = z/sg     -> da, dg
  *   dx[t] = W_proj^T dr[t] + sum_j (W_tanh_j^T da + W_sigmoid_j^T dg)[t - off_j]         -> dx (may be NULL)
  * dr may be NULL (residual output unused, e.g. the last block of the stack).
  * dr, da, dg: [B][Co8][ld]; dskip: [B][Ms8][ld]; dx: [B][Ci8][ld]. */
 int wn_block_backward_data(const wn_block_shape* s, const void* packed,
-                           const float* dr, const float* dskip, const float* ta, const float* sg,
+                           const float* dr, const float* dskip, const float* z, const float* sg,
                            float* da, float* dg, float* dx, wn_stream_t stream);
 
 /* ---- backward (weights): time/batch-summed outer products -> gradients in PyTorch layouts ---

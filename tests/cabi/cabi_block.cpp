@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
     wn_block_params P = {up(wt), up(bt), up(ws), up(bs), up(wr), up(br), up(wk), up(bk), up(wp), up(bp)};
     const size_t nx = wn_series_floats(B, Ci, ld), ny = wn_series_floats(B, Co, ld);
     float* dx_in = up(to_series(x, B, Ci, L, ld, halo));
-    float *r = dzero(ny), *sk = dzero(ny), *ta = dzero(ny), *sg = dzero(ny), *z = dzero(ny);
+    float *r = dzero(ny), *sk = dzero(ny), *sg = dzero(ny), *z = dzero(ny);
     float *dr = up(to_series(cr, B, Co, L, ld, halo)), *ds = up(to_series(cs, B, Co, L, ld, halo));
     float *da = dzero(ny), *dg = dzero(ny), *dx = dzero(nx);
     void* packed = nullptr;
@@ -74,8 +74,8 @@ int main(int argc, char** argv) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     WN(wn_block_pack(&s, &P, packed, st));
-    WN(wn_block_forward(&s, packed, dx_in, r, sk, 0, ta, sg, z, st));
-    WN(wn_block_backward_data(&s, packed, dr, ds, ta, sg, da, dg, dx, st));
+    WN(wn_block_forward(&s, packed, dx_in, r, sk, 0, sg, z, st));
+    WN(wn_block_backward_data(&s, packed, dr, ds, z, sg, da, dg, dx, st));
     WN(wn_block_backward_weights(&s, dx_in, z, da, dg, dr, ds, &G, wsp, wsb, st));
     CK(hipStreamSynchronize(st));
 

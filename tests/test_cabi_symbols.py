@@ -59,10 +59,10 @@ def test_shape_errors_are_reported_not_crashed():
     assert lib.wn_block_wgrad_workspace_bytes(ctypes.byref(ok)) > 0
     small_halo = _lib.BlockShape(1, 100, 8, 8, 8, 2, 8, 1, 4 + 128 + 4, 4)     # taps reach 8 > halo 4
     assert lib.wn_block_packed_bytes(ctypes.byref(small_halo)) == 0
-    assert lib.wn_block_forward(ctypes.byref(small_halo), None, None, None, None, 0, None, None, None, None) == -1
+    assert lib.wn_block_forward(ctypes.byref(small_halo), None, None, None, None, 0, None, None, None) == -1
     too_wide = _lib.BlockShape(1, 100, 8, 8, 8, 9, 1, 1, 8 + 128 + 8, 8)       # kernel_width 9 > WN_MAX_TAPS
-    assert lib.wn_block_forward(ctypes.byref(too_wide), None, None, None, None, 0, None, None, None, None) == -2
-    assert lib.wn_block_forward(ctypes.byref(ok), None, None, None, None, 0, None, None, None, None) == -3  # NULL ptrs
+    assert lib.wn_block_forward(ctypes.byref(too_wide), None, None, None, None, 0, None, None, None) == -2
+    assert lib.wn_block_forward(ctypes.byref(ok), None, None, None, None, 0, None, None, None) == -3  # NULL ptrs
 
 
 def test_missing_library_is_loud(monkeypatch):

@@ -58,7 +58,7 @@ SIGNATURES = {
     "wn_block_packed_bytes": (c_size_t, [POINTER(BlockShape)]),
     "wn_block_pack": (c_int, [POINTER(BlockShape), POINTER(BlockParams), c_void_p, c_void_p]),
     "wn_block_forward": (c_int, [POINTER(BlockShape), c_void_p, c_float_p, c_float_p, c_float_p, c_int,
-                                 c_float_p, c_float_p, c_float_p, c_void_p]),
+                                 c_float_p, c_float_p, c_void_p]),
     "wn_skipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape)]),
     "wn_skipsum_pack": (c_int, [POINTER(SkipSumShape), POINTER(c_void_p), c_float_p, c_void_p, c_void_p]),
     "wn_skipsum_forward": (c_int, [POINTER(SkipSumShape), c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),

@@ -208,7 +208,7 @@ BlockPlan plan_block(const wn_block_shape* s) {
         GemmPlan& g = p.ka;
         const int zt = tiles32(Co);
         g.MT = pick_mt(zt);
-        // dz has the shortest K loop (2C) and the heaviest epilogue (reads ta, sg, writes da, dg): 64-row slabs at two waves
+        // dz has the shortest K loop (2C) and the heaviest epilogue (reads z, sg, writes da, dg): 64-row slabs at two waves
         // per SIMD let one wave's epilogue overlap the other's MFMAs: 0.616 -> 0.589 ms per launch at 256 ch x 16 x 16000
         // (WN_DZ_MT=4 restores the 128-row slabs for A/B runs)
         static const int dz_mt = getenv("WN_DZ_MT") ? atoi(getenv("WN_DZ_MT")) : 2;
@@ -443,22 +443,21 @@ int wn_block_pack(const wn_block_shape* s, const wn_block_params* p, void* packe
 }
 
 int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x, float* r_out, float* skip,
-                     int skip_accumulate, float* ta, float* sg, float* z, wn_stream_t stream) {
+                     int skip_accumulate, float* sg, float* z, wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_block(s, off);
     if (rc != WN_OK) return rc;
     if (!packed || !x || !z) return WN_ERR_NULL;
-    if ((ta == nullptr) != (sg == nullptr)) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const BlockPlan bp = plan_block(s);
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     const double BL = (double)s->batch * s->length;
     GemmArgs a;
-    {   // a,g = dilated convs ; ta, sg, z
+    {   // a,g = dilated convs ; sg, z
         const GemmPlan& g = bp.fa;
         fill_gemm_common(a, g, packed, bp.off_fa, 0, g.nslab, s->batch, s->length, s->ld, s->halo);
         for (int j = 0; j < k; ++j) set_seg(a, j, x, Ci, off[j], g.seg_nkb[j]);
-        a.ta = ta; a.sg = sg; a.z = z; a.gate_cp = cp8(Co); a.gate_rows = Co;
+        a.sg = sg; a.z = z; a.gate_cp = cp8(Co); a.gate_rows = Co;
         ProfScope prof(KC_GATE_GEMM, 2.0 * (2.0 * Co) * (double)(k * Ci) * BL, st);
         WN_HIP(launch_gemm(g.MT, EPI_GATE, a, st), "series_gemm<gate>");
     }
@@ -488,11 +487,11 @@ int wn_block_forward(const wn_block_shape* s, const void* packed, const float* x
 }
 
 int wn_block_backward_data(const wn_block_shape* s, const void* packed, const float* dr, const float* dskip,
-                           const float* ta, const float* sg, float* da, float* dg, float* dx, wn_stream_t stream) {
+                           const float* z, const float* sg, float* da, float* dg, float* dx, wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_block(s, off);
     if (rc != WN_OK) return rc;
-    if (!packed || !dskip || !ta || !sg || !da || !dg) return WN_ERR_NULL;
+    if (!packed || !dskip || !z || !sg || !da || !dg) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const BlockPlan bp = plan_block(s);
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
@@ -506,7 +505,7 @@ int wn_block_backward_data(const wn_block_shape* s, const void* packed, const fl
         set_seg(a, 1, dr, Co, 0, g.seg_nkb[1]);
         const int nseg = dr ? 2 : 1;
         for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = nseg;
-        a.ta = const_cast<float*>(ta); a.sg = const_cast<float*>(sg); a.da = da; a.dg = dg;
+        a.z = const_cast<float*>(z); a.sg = const_cast<float*>(sg); a.da = da; a.dg = dg;
         a.gate_cp = cp8(Co); a.gate_rows = Co;
         ProfScope prof(KC_DZ_GEMM, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
         WN_HIP(launch_gemm(g.MT, EPI_DGATE, a, st), "series_gemm<dz>");

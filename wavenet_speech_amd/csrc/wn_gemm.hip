@@ -285,27 +285,24 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
             for (int r = 0; r < 16; ++r) {
                 const int ch = sl.row0 + 32 * i + rowof(r, h);
                 if (ch < a.gate_rows) {
-                    breg_t vt, vs, vz;
+                    breg_t vs, vz;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float tt = tanh_f(acc[2 * i][t][r]);
                         const float ss = sigmoid_f(acc[2 * i + 1][t][r]);
-                        vt[t] = tt;
                         vs[t] = ss;
                         vz[t] = tt * ss;
                     }
                     const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
                     *reinterpret_cast<breg_t*>(a.z + o) = clip(vz);
-                    if (a.ta) {
-                        *reinterpret_cast<breg_t*>(a.ta + o) = clip(vt);
-                        *reinterpret_cast<breg_t*>(a.sg + o) = clip(vs);
-                    }
+                    // training keeps sigmoid(g) beside z for the backward pass; tanh(a) is recovered there as z / sigmoid(g)
+                    if (a.sg) *reinterpret_cast<breg_t*>(a.sg + o) = clip(vs);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-    } else {  // EPI_DGATE: acc = dz ; da = dz*sg*(1-ta^2), dg = dz*ta*sg*(1-sg)
-        // ta/sg come from HBM: issue a whole batch of rows (up to 32 x 16 B per lane in flight) before using any of
+    } else {  // EPI_DGATE: acc = dz ; da = dz*sg*(1-ta^2), dg = dz*ta*sg*(1-sg) with ta = z / sg
+        // z/sg come from HBM: issue a whole batch of rows (up to 32 x 16 B per lane in flight) before using any of
         // them -- row-by-row load->use chains cost 55 us of a 186 us wave (tools/block_stamps.py).
         constexpr int RB = (MT == 4) ? 8 : 4;   // rows per batch: 2 x RB x 16 B per lane in flight, one batch ahead
         constexpr int BPT = 16 / RB;            // batches per 32-row tile
@@ -318,7 +315,7 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
                 int ch = sl.row0 + 32 * m + rowof(r0 + i, h);
                 ch = ch < a.gate_rows ? ch : a.gate_rows - 1;   // clamp (never stored), no branch
                 const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
-                ft[i] = *reinterpret_cast<const breg_t*>(a.ta + o);
+                ft[i] = *reinterpret_cast<const breg_t*>(a.z + o);      // z = tanh(a) sigmoid(g)
                 fs[i] = *reinterpret_cast<const breg_t*>(a.sg + o);
             }
         };
@@ -334,13 +331,16 @@ __global__ __launch_bounds__(64, WPS) void series_gemm_kernel(const GemmArgs a) 
                 const int ch = sl.row0 + 32 * m + rowof(r, h);
                 if (ch < a.gate_rows) {
                     const long o = ((long)b * a.gate_cp + ch) * ld + colbase;
-                    const breg_t ta_ = vt[bi & 1][i], sg_ = vs[bi & 1][i];
+                    const breg_t z_ = vt[bi & 1][i], sg_ = vs[bi & 1][i];
                     breg_t va, vg;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
+                        // tanh = z / sigmoid (not stored): da = dz s (1 - t^2) = dz (s - z t), dg = dz t s (1 - s) = dz z (1 - s);
+                        // s = 0 (sigmoid underflow) has z = 0 and both gradients 0
                         const float dz = acc[m][t][r];
-                        va[t] = dz * sg_[t] * (1.0f - ta_[t] * ta_[t]);
-                        vg[t] = dz * ta_[t] * sg_[t] * (1.0f - sg_[t]);
+                        const float tt = sg_[t] > 0.0f ? z_[t] / sg_[t] : 0.0f;
+                        va[t] = dz * (sg_[t] - z_[t] * tt);
+                        vg[t] = dz * z_[t] * (1.0f - sg_[t]);
                     }
                     *reinterpret_cast<breg_t*>(a.da + o) = clip(va);
                     *reinterpret_cast<breg_t*>(a.dg + o) = clip(vg);

@@ -54,7 +54,6 @@ struct GemmArgs {
     GemmSlab slab[kMaxSlab];
     GemmDst dst[kMaxDst];
     // gate epilogues (channel-indexed series with cp = gate_cp)
-    float* ta;        // EPI_GATE out / EPI_DGATE in
     float* sg;
     float* z;         // EPI_GATE out
     float* da;        // EPI_DGATE out

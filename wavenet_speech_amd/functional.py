@@ -107,11 +107,11 @@ def _pack_block(lib, shape, params, device):
     return packed
 
 
-def _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dskip, want_dx, layout, batch, device):
+def _block_backward(lib, shape, spec, packed, x, sg, z, dr, dskip, want_dx, layout, batch, device):
     """bwd-data + bwd-weights of one block; returns (dx lease or None, [10 gradient tensors])"""
     da, dg = Lease(batch, spec.co, layout, device), Lease(batch, spec.co, layout, device)
     dx = Lease(batch, spec.ci, layout, device) if want_dx else None
-    _lib.check(lib.wn_block_backward_data(ctypes.byref(shape), _p(packed), _p(dr), _p(dskip), _p(ta), _p(sg),
+    _lib.check(lib.wn_block_backward_data(ctypes.byref(shape), _p(packed), _p(dr), _p(dskip), _p(z), _p(sg),
                                           _p(da), _p(dg), _p(dx), _stream()), "wn_block_backward_data")
     k = spec.k
     shapes = [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
@@ -197,23 +197,23 @@ class _ResidualStackFn(torch.autograd.Function):
                 packed = _pack_block(lib, shape, params, dev)
             r = Lease(B, spec.co, layout, dev) if l + 1 < n else None  # the last residual output is never used
             if training:
-                ta, sg, z = (Lease(B, spec.co, layout, dev) for _ in range(3))
+                sg, z = (Lease(B, spec.co, layout, dev) for _ in range(2))   # kept for backward; tanh = z / sg
             else:
-                ta = sg = None
+                sg = None
                 if zbuf is None or zbuf.channels != spec.co:
                     zbuf = Lease(B, spec.co, layout, dev)
                 z = zbuf
             # training keeps every block's z, so skips_sum is formed afterwards by one long-K product over all
             # blocks (wn_skipsum_forward); inference accumulates per block and keeps a single z scratch buffer
             _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(cur), _p(r), None if training else _p(S),
-                                            1, _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
+                                            1, _p(sg), _p(z), _stream()), "wn_block_forward")
             if training:
-                saved.append((cur, ta, sg, z, packed, shape))
+                saved.append((cur, sg, z, packed, shape))
                 skip_w.append(params[6])
                 skip_b.append(params[7])
             cur = r
         if training:
-            _stack_skip_sum(lib, specs, [sv[3] for sv in saved], skip_w, skip_b, S, B, layout, dev)
+            _stack_skip_sum(lib, specs, [sv[2] for sv in saved], skip_w, skip_b, S, B, layout, dev)
         ctx.specs, ctx.saved, ctx.layout, ctx.batch = specs, saved, layout, B
         ctx.param_shapes = [tuple(t.shape) for t in flat]
         # hand autograd a tensor of its own: views of internal buffers must never escape a custom Function
@@ -232,9 +232,9 @@ class _ResidualStackFn(torch.autograd.Function):
         grads_flat = [None] * (len(specs) * PARAMS_PER_BLOCK)
         for l in range(len(specs) - 1, -1, -1):
             spec = specs[l]
-            x, ta, sg, z, packed, shape = ctx.saved[l]
+            x, sg, z, packed, shape = ctx.saved[l]
             want_dx = l > 0 or ctx.needs_input_grad[0]
-            dx, grads = _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, dS, want_dx, layout, B, dev)
+            dx, grads = _block_backward(lib, shape, spec, packed, x, sg, z, dr, dS, want_dx, layout, B, dev)
             grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
             dr = dx
             ctx.saved[l] = None  # release this block's activations to the pool
@@ -303,12 +303,12 @@ class _ResidualBlockFn(torch.autograd.Function):
         r = Lease(B, spec.co, layout, dev)
         s = Lease(B, spec.ms, layout, dev)
         training = bool(grad_enabled) and any(ctx.needs_input_grad)
-        ta, sg = (Lease(B, spec.co, layout, dev), Lease(B, spec.co, layout, dev)) if training else (None, None)
+        sg = Lease(B, spec.co, layout, dev) if training else None
         z = Lease(B, spec.co, layout, dev)
         _lib.check(lib.wn_block_forward(ctypes.byref(shape), _p(packed), _p(xin), _p(r), _p(s), 0,
-                                        _p(ta), _p(sg), _p(z), _stream()), "wn_block_forward")
+                                        _p(sg), _p(z), _stream()), "wn_block_forward")
         if training:
-            ctx.saved = (xin, ta, sg, z, packed, shape)
+            ctx.saved = (xin, sg, z, packed, shape)
         ctx.spec, ctx.layout, ctx.batch = spec, layout, B
         ctx.param_shapes = [tuple(t.shape) for t in params]
         return _own(r.view()), _own(s.view())
@@ -320,11 +320,11 @@ class _ResidualBlockFn(torch.autograd.Function):
         lib = _lib.load()
         spec, layout, B = ctx.spec, ctx.layout, ctx.batch
         dev = d_r.device
-        x, ta, sg, z, packed, shape = ctx.saved
+        x, sg, z, packed, shape = ctx.saved
         dr, ds = Lease(B, spec.co, layout, dev), Lease(B, spec.ms, layout, dev)
         load_series(dr.t, d_r, layout)
         load_series(ds.t, d_s, layout)
-        dx, grads = _block_backward(lib, shape, spec, packed, x, ta, sg, z, dr, ds, ctx.needs_input_grad[0], layout, B, dev)
+        dx, grads = _block_backward(lib, shape, spec, packed, x, sg, z, dr, ds, ctx.needs_input_grad[0], layout, B, dev)
         grads = [g.view(shp) for g, shp in zip(grads, ctx.param_shapes)]
         dx0 = _own(dx.view()) if dx is not None else None
         ctx.saved = None
