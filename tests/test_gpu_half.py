@@ -108,12 +108,13 @@ def test_plain_half_modes_vs_oracle(precision):
 
 
 @pytest.mark.parametrize("precision,c,dims,L,B", [("f16x3", 256, (1, 2, 64), 384, 2), ("f16x3", 128, (1, 3), 256, 3),
+                                                  ("f16x3", 256, (3, 1), 400, 2), ("f16x3", 256, (1,), 16, 1),
                                                   ("f16", 256, (1, 4), 256, 2), ("bf16", 256, (2, 1), 384, 1),
                                                   ("f16x3", 512, (1, 130), 128, 1)])
 def test_full_tile_shapes_take_the_16x16x32_gemm(precision, c, dims, L, B):
-    """rows a multiple of 256 (gate: channels a multiple of 128) and L a multiple of 128 select hgemm8_kernel in the f16x3 mode
-    (256 x 128 tiles on v_mfma_f32_16x16x32, 32-channel k-steps, its own weight packing): all four epilogues against the
-    oracle.  By default that is the gate and skips_sum GEMMs; test_every_gemm_and_mode_on_the_16x16x32_kernel runs the same
+    """rows a multiple of 256 (gate: channels a multiple of 128) and L a multiple of 16 select hgemm8_kernel in the f16x3 mode
+    (256 x 256 tiles on v_mfma_f32_16x16x32, 32-channel k-steps, its own weight packing; L = 400 and 16 leave a partial last
+    tile): all four epilogues against the oracle.  By default that is the gate and skips_sum GEMMs; test_every_gemm_and_mode_on_the_16x16x32_kernel runs the same
     cases with WN_HGEMM16=2 (every GEMM, every mode) in a child process; WN_HGEMM16=0 keeps every shape on hgemm_kernel."""
     layers = [(c, c, 2, d) for d in dims]
     net = _cond_wavenet(c, layers, seed=c + L)
@@ -149,7 +150,7 @@ def test_every_gemm_and_mode_on_the_16x16x32_kernel():
     env = dict(os.environ, WN_HGEMM16="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_half.py"), "-q", "-x", "-k",
                         "full_tile or two_skips_sum"], env=env, cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert r.returncode == 0 and "8 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
 
 
 def test_half_inference_matches_training_forward_and_is_deterministic():

@@ -702,16 +702,19 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
 // HPlan::init); everything else stays on hgemm_kernel.  Weights are packed [k-step of 32][plane][k-group 4][row 256][8].
 constexpr int kHCol8 = 128;
 
-template <int P, bool BF, int EPI>
+// NT = accumulator tiles per wave along time.  8 -> 256 x 256 workgroup tiles, 64 x 128 per wave, TWO 64 KiB stages with the
+// whole next stage issued at the start of the current one (f16x3: the variant in use); 4 -> 256 x 128 tiles, 64 x 64 per wave,
+// three stages (the first version; a third more LDS read traffic and half again the staging per FLOP: gate 0.407 vs 0.350 ms).
+template <int P, bool BF, int EPI, int NT>
 __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
-    constexpr int ROWS = 256, COLS = kHCol8;
+    constexpr int ROWS = 256, COLS = 32 * NT;
     constexpr int A_PLANE = 4 * ROWS * 16, B_PLANE = 4 * COLS * 16;
     constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;   // 48 KiB at f16x3, 24 KiB one plane
     constexpr int D = (163840 / STAGE) > 6 ? 6 : (163840 / STAGE);                            // 3 / 6 stages
     constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192;                               // 1 KiB pieces per wave and stage
     constexpr int PW = A_PW + B_PW;
     constexpr int INFLIGHT = (D - 2) * PW;
-    constexpr int NPAIR = 16;
+    constexpr int NPAIR = 4 * NT;
     static_assert(INFLIGHT < 64, "vmcnt is a 6-bit counter");
     static_assert(B_PW >= 1, "piece split");
     __shared__ __attribute__((aligned(1024))) char lds[D * STAGE];
@@ -751,8 +754,9 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
             const int piece = wave + 8 * PI;                                  // the weight image of a stage is contiguous
             WN_GLDS(a_src + (long long)is_ks * A_BYTES + piece * 1024, lane16, stage + piece * 1024);
         } else {
-            const int q = wave + 8 * (PI - A_PW);                             // (plane, k-group, column half)
-            const int hc = q & 1, kg = (q >> 1) & 3, p = q >> 3;
+            constexpr int HC = COLS / 64;                                     // 64-column pieces per (plane, k-group)
+            const int q = wave + 8 * (PI - A_PW);                             // (plane, k-group, column piece)
+            const int hc = q % HC, kg = (q / HC) & 3, p = q / (4 * HC);
             WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + hc * 1024, lane16,
                     stage + A_BYTES + ((p * 4 + kg) * COLS + 64 * hc) * 16);
         }
@@ -777,11 +781,11 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
         issue_advance();
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NT];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[m][n][q] = 0.0f;
 
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
 
     // fragment of v_mfma_f32_16x16x32: lane (c16, rq) holds row / column c16, k = 8 rq .. 8 rq + 7 = k-group rq of the stage
     const unsigned a_rd = (unsigned)((rq * ROWS + wm * 64 + c16) * 16);
-    const unsigned b_rd = (unsigned)(A_BYTES + (rq * COLS + wn * 64 + c16) * 16);
+    const unsigned b_rd = (unsigned)(A_BYTES + (rq * COLS + wn * 16 * NT + c16) * 16);
 
     int slot = 0;
     for (int ks = 0; ks < nks; ++ks) {
@@ -811,11 +815,11 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
         const int wslot = slot == 0 ? D - 1 : slot - 1;
         const char* st = lds + slot * STAGE;
         char* wst = lds + wslot * STAGE;
-        V8 af[4][P], bf[4][P];
+        V8 af[4][P], bf[NT][P];
         auto read_for = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
             if constexpr (t < NPAIR) {
-                constexpr int m = t / 4, n = t % 4;
+                constexpr int m = t / NT, n = t % NT;
                 if constexpr (n == 0) {
 #pragma unroll
                     for (int p = 0; p < P; ++p) af[m][p] = *reinterpret_cast<const V8*>(st + a_rd + p * A_PLANE + m * 256);
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
-                constexpr int idx = I, m = idx / 4, n = idx % 4;
+                constexpr int idx = I, m = idx / NT, n = idx % NT;
                 read_for(std::integral_constant<int, idx + 2>{});
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (BF) {
@@ -846,7 +850,8 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 [&]<int... Q>(std::integer_sequence<int, Q...>) {
                     ([&] {
-                        if constexpr ((Q * NPAIR) / PW == idx) {
+                        // two stages: the whole next stage is issued at the start of this one (piece Q after tile Q); else spread
+                        if constexpr (D == 2 ? (Q == idx) : ((Q * NPAIR) / PW == idx)) {
                             issue_piece(wst, std::integral_constant<int, Q>{});
                             __builtin_amdgcn_sched_barrier(0);
                         }
@@ -863,19 +868,23 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sum += acc[m][n][q];
         if (sum == 1.2345e-30f && a.flag) a.flag[0] = 7;
         return;
     }
 
-    // ---- epilogue (full tiles only: straight-line code) ---------------------------------------------------------------
+    // ---- epilogue ----------------------------------------------------------------------------------------------------
     // C/D layout of the 16x16 tile: column = lane & 15, rows 4 (lane >> 4) + q: four consecutive channels = one 8-byte piece
-    // of the unit (group 2 m + (rq >> 1) of the wave's eight, half rq & 1).
+    // of the unit (group 2 m + (rq >> 1) of the wave's eight, half rq & 1).  Rows are always whole tiles (the plan sees to it);
+    // along time L is a multiple of 16, so a 16-column accumulator tile is either wholly inside the utterance or wholly
+    // outside: `nok(n)` is wave-uniform and the only condition in here (it guards stores; loads past L stay inside the row).
     const float osc = a.oscale;
     unsigned ovf = 0;
-    const long long col = ((long long)a.halo + t0 + wn * 64 + c16) * 16 + 8 * (rq & 1);
+    const long long col = ((long long)a.halo + t0 + wn * 16 * NT + c16) * 16 + 8 * (rq & 1);
+    const int c_first = t0 + wn * 16 * NT;
+    auto nok = [&](int n) { return c_first + 16 * n < a.L; };
     if constexpr (EPI == HEPI_STORE) {
         const HDst d = a.dst[sl.dst];
         char* dbase = d.base + (long long)b * d.ustride + col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
@@ -883,11 +892,11 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
         for (int m = 0; m < 4; ++m) {
             char* prow = dbase + (long long)(2 * m) * ld * 16;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = acc[m][n][q] * osc + bvec[m][q];
-                store4<P, BF>(prow + n * 256, d.pstride, v, ovf);
+                if (nok(n)) store4<P, BF>(prow + n * 256, d.pstride, v, ovf);
             }
         }
     } else if constexpr (EPI == HEPI_GATE) {
@@ -899,98 +908,98 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float vt[4], vs[4], vz[4];
+            for (int n = 0; n < NT; ++n) {
+                float vs[4], vz[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    vt[q] = h_tanh(acc[m][n][q] * osc + bvec[m][q]);
+                    const float vt = h_tanh(acc[m][n][q] * osc + bvec[m][q]);
                     vs[q] = h_sigmoid(acc[m + 2][n][q] * osc + bvec[m + 2][q]);
-                    vz[q] = vt[q] * vs[q];
+                    vz[q] = vt * vs[q];
                 }
                 const long long on = (long long)(2 * m) * ld * 16 + n * 256;
-                store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
-                if (keep) store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
+                if (nok(n)) {
+                    store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
+                    if (keep) store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);
+                }
             }
     } else if constexpr (EPI == HEPI_DGATE) {
         typedef typename HT<BF>::v4 V4;
         const long long o0 = col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
-        const char* tab = a.z.base + (long long)b * a.z.ustride + o0;            // z = tanh * sigmoid (the tanh itself is not stored)
+        const char* zb = a.z.base + (long long)b * a.z.ustride + o0;          // z = tanh * sigmoid (the tanh itself is not stored)
         const char* sgb = a.sg.base + (long long)b * a.sg.ustride + o0;
         char* dab = a.da.base + (long long)b * a.da.ustride + o0;
         char* dgb = a.dg.base + (long long)b * a.dg.ustride + o0;
-        V4 rt[2][4][P], rs[2][4][P];                       // raw tanh / sigmoid of a 16-row tile, one tile ahead
-        auto fetch = [&](int m, V4 (&ft)[4][P], V4 (&fs)[4][P]) {
-            const long long o = (long long)(2 * m) * ld * 16;
+        constexpr int NH = NT / 4;                         // groups of four column tiles per 16-row tile
+        constexpr int NG = 4 * NH;
+        V4 rz[2][4][P], rs[2][4][P];                       // raw z / sigmoid of one group, one group ahead of the stores
+        auto fetch = [&](int g, V4 (&fz)[4][P], V4 (&fs)[4][P]) {
+            const long long o = (long long)(2 * (g / NH)) * ld * 16 + (g % NH) * 1024;
 #pragma unroll
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    ft[n][p] = *reinterpret_cast<const V4*>(tab + o + n * 256 + p * a.z.pstride);
+                    fz[n][p] = *reinterpret_cast<const V4*>(zb + o + n * 256 + p * a.z.pstride);
                     fs[n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 256 + p * a.sg.pstride);
                 }
         };
-        fetch(0, rt[0], rs[0]);
+        fetch(0, rz[0], rs[0]);
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ([&] {
+                constexpr int g = G, m = g / NH, nh = g % NH;
+                if constexpr (g + 1 < NG) fetch(g + 1, rz[(g + 1) & 1], rs[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const long long o = (long long)(2 * m) * ld * 16 + nh * 1024;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (m + 1 < 4) fetch(m + 1, rt[(m + 1) & 1], rs[(m + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            const long long o = (long long)(2 * m) * ld * 16;
+                for (int n = 0; n < 4; ++n) {
+                    float va[4], vg[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                float va[4], vg[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float z_ = (float)rt[m & 1][n][0][q], s_ = (float)rs[m & 1][n][0][q];
-                    if constexpr (P == 2) { z_ += (float)rt[m & 1][n][1][q]; s_ += (float)rs[m & 1][n][1][q]; }
-                    const float dz = acc[m][n][q] * osc;
-                    dgate(dz, z_, s_, va[q], vg[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        float z_ = (float)rz[g & 1][n][0][q], s_ = (float)rs[g & 1][n][0][q];
+                        if constexpr (P == 2) { z_ += (float)rz[g & 1][n][1][q]; s_ += (float)rs[g & 1][n][1][q]; }
+                        dgate(acc[m][4 * nh + n][q] * osc, z_, s_, va[q], vg[q]);
+                    }
+                    if (nok(4 * nh + n)) {
+                        store4<P, BF>(dab + o + n * 256, a.da.pstride, va, ovf);
+                        store4<P, BF>(dgb + o + n * 256, a.dg.pstride, vg, ovf);
+                    }
                 }
-                store4<P, BF>(dab + o + n * 256, a.da.pstride, va, ovf);
-                store4<P, BF>(dgb + o + n * 256, a.dg.pstride, vg, ovf);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, NG>{});
     } else {   // HEPI_F32: dense fp32 [B][rows][L]
         const float dsc = osc * (a.dyn_inv ? a.dyn_inv[0] : 1.0f);
-        float* pbase = a.out32 + ((long long)b * a.out32_rows + sl.row0 + wm * 64 + 4 * rq) * a.L + t0 + wn * 64 + c16;
-        if (a.out32_accum) {   // the second skips_sum group of a > 32-block stack: all 64 reads in flight, then add and store
-            float old[4][4][4];
+        float* pbase = a.out32 + ((long long)b * a.out32_rows + sl.row0 + wm * 64 + 4 * rq) * a.L + c_first + c16;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                float* prow = pbase + (long long)(16 * m + q) * a.L;
+                if (a.out32_accum) {   // the second skips_sum group of a > 32-block stack: a row's reads in flight, then add and store
+                    float old[NT];
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) old[m][q][n] = pbase[(long long)(16 * m + q) * a.L + 16 * n];
+                    for (int n = 0; n < NT; ++n) old[n] = nok(n) ? prow[16 * n] : 0.0f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                    for (int n = 0; n < NT; ++n)
+                        if (nok(n)) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q] + old[n];
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        pbase[(long long)(16 * m + q) * a.L + 16 * n] = acc[m][n][q] * dsc + bvec[m][q] + old[m][q][n];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float* prow = pbase + (long long)(16 * m + q) * a.L;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q];
+                    for (int n = 0; n < NT; ++n)
+                        if (nok(n)) prow[16 * n] = acc[m][n][q] * dsc + bvec[m][q];
                 }
-        }
+            }
     }
     if constexpr (!BF) {
         if (ovf && a.flag) atomicOr(a.flag, 1u);
     }
 }
 
-template <int P, bool BF>
+template <int P, bool BF, int NT>
 static hipError_t launch_h8(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
     switch (epi) {
-        case HEPI_STORE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_STORE>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_STORE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_STORE, NT>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE, NT>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE, NT>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32, NT>), dim3(grid), dim3(512), 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1030,14 +1039,20 @@ hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStr
     HGemmArgs a = a_in;
     static const int dbg = getenv("WN_HGEMM_DBG") ? atoi(getenv("WN_HGEMM_DBG")) : 0;
     a.dbg = dbg;
-    if (MT == 8) {   // hgemm8_kernel: the plan guarantees full 256 x 128 tiles
+    if (MT == 9) {   // hgemm8_kernel, 256 x 256 tiles (f16x3): whole 16-column accumulator tiles, the last tile of a row may be partial
+        if (a.L % 16 != 0 || prec != HP_F16X3) return hipErrorInvalidValue;
+        a.tiles_per_row = (a.L + 255) / 256;
+        a.ncol = a.B * a.tiles_per_row;
+        return launch_h8<2, false, 8>(epi, a, (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8)), st);
+    }
+    if (MT == 8) {   // hgemm8_kernel, 256 x 128 tiles: full tiles only
         if (a.L % kHCol8 != 0) return hipErrorInvalidValue;
         a.tiles_per_row = a.L / kHCol8;
         a.ncol = a.B * a.tiles_per_row;
         const unsigned grid8 = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));
-        if (prec == HP_F16X3) return launch_h8<2, false>(epi, a, grid8, st);
-        if (prec == HP_F16) return launch_h8<1, false>(epi, a, grid8, st);
-        if (prec == HP_BF16) return launch_h8<1, true>(epi, a, grid8, st);
+        if (prec == HP_F16X3) return launch_h8<2, false, 4>(epi, a, grid8, st);
+        if (prec == HP_F16) return launch_h8<1, false, 4>(epi, a, grid8, st);
+        if (prec == HP_BF16) return launch_h8<1, true, 4>(epi, a, grid8, st);
         return hipErrorInvalidValue;
     }
     a.tiles_per_row = (a.L + kHCol - 1) / kHCol;

@@ -85,22 +85,27 @@ struct HPlan {
     //            store bursts (gate writes three tensors) that overlap the other workgroup's K loop: gate 0.510 -> 0.467 ms,
     //            dz 0.370 -> 0.302, res 0.242 -> 0.229, dx 0.413 -> 0.403
     //   long_k = true  (skips_sum, K = 30 C): 256-row tiles, one workgroup per CU -- half the weight re-staging: 2.20 vs 2.53 ms
-    //   hgemm8_kernel (k32): the 16x16x32 MFMA shape sustains a higher clock at the power limit; it takes FULL 256 x 128 tiles
-    //            only (row count a multiple of 256, L a multiple of 128: cfg3, cfg5).  Measured against hgemm_kernel at cfg3,
-    //            f16x3, alternating runs on one device, on two devices: gate 0.407 vs 0.426 / 0.426 vs 0.425 ms, skips_sum
-    //            2.04 vs 2.14 / 2.20 vs 2.25, res 0.196 vs 0.197 / 0.202 vs 0.198, dz equal, dx 0.366 vs 0.361 / 0.395 vs
-    //            0.377; whole step 65.1 vs 67.0 / 68.0 vs 67.8 ms.  So `prefer` is set for the gate and skips_sum GEMMs only;
-    //            the one-plane modes lose with it (cfg5 f16 89.1 vs 84.7 ms/step: 16 MFMAs per wave between barriers).
-    //            WN_HGEMM16=0: never; =2: wherever the shape allows, every mode (tests).
+    //   hgemm8_kernel (k32): the 16x16x32 MFMA shape sustains a higher clock at the power limit.  One eight-wave workgroup
+    //            per CU on a 256-row tile, weights packed in 32-channel k-steps.  f16x3 runs it on 256 x 256 tiles (`wide`,
+    //            two stages; L a multiple of 16); the 256 x 128 / three-stage form needs L a multiple of 128.  Measured
+    //            against hgemm_kernel at cfg3 (alternating runs on one device, ms per launch): gate 0.363 vs 0.386, skips_sum
+    //            2.03 vs 2.24, dx 0.381 vs 0.380, res 0.201 vs 0.199, dz 0.317 vs 0.300; step 65.5 vs 66.7 ms -> `prefer` is set
+    //            for the gate and skips_sum GEMMs.  The one-plane modes lose with it (cfg5 f16 89.1 vs 84.7 ms/step).
+    //            WN_HGEMM16=0: never; =2: wherever the shape allows, every mode (tests); WN_HGEMM16_COLS=128: narrow form.
+    int wide = 0;
     void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool prefer_k32 = false) {
         static const int knob = getenv("WN_HGEMM16") ? atoi(getenv("WN_HGEMM16")) : 1;
-        const bool fits = out_rows % 256 == 0 && length > 0 && length % 128 == 0;
-        k32 = (fits && (knob == 2 || (knob == 1 && prefer_k32 && planes_ == 2))) ? 1 : 0;
+        static const bool narrow_only = getenv("WN_HGEMM16_COLS") && atoi(getenv("WN_HGEMM16_COLS")) == 128;
+        const bool rows_ok = out_rows % 256 == 0 && length > 0;
+        const bool fits_wide = rows_ok && planes_ == 2 && length % 16 == 0 && !narrow_only;
+        const bool fits_narrow = rows_ok && length % 128 == 0;
+        k32 = ((knob == 2 && (fits_wide || fits_narrow)) || (knob == 1 && prefer_k32 && planes_ == 2 && (fits_wide || fits_narrow))) ? 1 : 0;
+        wide = (k32 && fits_wide) ? 1 : 0;
         MT = (k32 || (long_k && out_rows > 128)) ? 4 : 2;
         rows = 64 * MT;
         planes = planes_;
     }
-    int kernel() const { return k32 ? 8 : MT; }              // what launch_hgemm is told
+    int kernel() const { return k32 ? (wide ? 9 : 8) : MT; } // what launch_hgemm is told
     int wave_rows() const { return k32 ? 4 : 2; }            // wave rows of the workgroup (each wave owns rows / wave_rows rows)
     bool add_slab(int nseg_used, int row0) {
         if (nslab >= kHMaxSlab) return false;
