@@ -196,6 +196,119 @@ __global__ __launch_bounds__(256, 1) void loop_kernel(const char* src, float* ou
     }
 }
 
+// Eight-wave form of the 16x16x32 loop: 2 x 4 waves, 128 x 64 accumulator tiles per wave (8 x 4 MFMA tiles, 128 registers), two
+// waves per SIMD; same 64 KiB stages, two of them, 8 DMA pieces per wave and stage issued at the start of the stage.
+__global__ __launch_bounds__(512, 1) void loop8_kernel(const char* src, float* out, unsigned long long* stamps, int nks, int ld,
+                                                        long long tensor_bytes) {
+    constexpr int WM = 8, WN = 4, NPAIR = WM * WN, TB = 1024, PW8 = 8;
+    __shared__ __attribute__((aligned(1024))) char lds[4 * STAGE];      // two stages of two 32 KiB images
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    for (int i = tid; i < 4 * STAGE / 16; i += 512)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[(i + 977 * blockIdx.x) & 0xfffff];
+    __syncthreads();
+    const int gq = (lane >> 3) & 3, tq = 8 * (lane >> 5) + ((lane & 7) ^ (4 * (((lane >> 3) & 3) >> 1)));
+    const unsigned lane_src = (unsigned)((gq * ld + tq) * 16);
+    const int pair = blockIdx.x % 7, split = blockIdx.x / 7;
+    const char* ta = src + (long long)(pair & 3) * tensor_bytes;
+    const char* tb = src + (long long)(4 + (pair & 1)) * tensor_bytes;
+    const long long pstride = (long long)32 * ld * 16, ustride = 2 * pstride;
+    int is_step = (int)(16000ll * split / (gridDim.x / 7));
+    auto issue_piece = [&](char* stage, auto pic) {      // 16 pieces of a 32 KiB image: wave w takes pieces w and w + 8
+        constexpr int PI = decltype(pic)::value;          // 0..7: image = PI / 2 (0, 1 of the first 16 steps; 2, 3 of the second), half = PI & 1
+        constexpr int img = PI / 4, sub = PI % 4;
+        const int piece = wave + 8 * (sub & 1);           // 0..15
+        constexpr int pl = sub >> 1;
+        const bool isB = (piece & 1) != 0;
+        const int step = min(is_step + img, 15999);       // the second image holds the next 16 time steps (never past the last utterance)
+        const int sb = step / 1000, st = (step - sb * 1000) * 16;
+        const char* sp = (isB ? tb : ta) + (long long)sb * ustride + pl * pstride + ((long long)(4 * (piece >> 1)) * ld + 256 + st) * 16;
+        glds16(sp, lane_src, stage + img * STAGE + (isB ? A_BYTES : 0) + pl * T_PLANE + (piece >> 1) * 1024);
+    };
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][n][q] = 0.0f;
+    const int h = lane >> 5, sg = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+    const int gr = 2 * sg + (pp >> 1);
+    const unsigned rd = (unsigned)((32 * h + 8 * gr + (q4 ^ (4 * (gr >> 1)))) * 16 + 8 * (pp & 1));
+    const int hi_off = (gr >> 1) ? -64 : 64;
+    {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (issue_piece(lds, std::integral_constant<int, I>{}), ...); }
+        (std::make_integer_sequence<int, PW8>{});
+        if (is_step < 15998) is_step += 2;
+    }
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    int slot = 0;
+    u32x4 af[WM][2], bf[WN][2];
+    for (int ks = 0; ks < nks; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* wst = lds + (slot ^ 2) * STAGE;
+        const char* sa = lds + slot * STAGE + rd + (wm * WM / 2) * TB;       // addresses only model the traffic
+        const char* sbb = lds + slot * STAGE + A_BYTES + rd + (wn * WN / 2) * TB;
+        auto read_for = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < NPAIR) {
+                constexpr int m = t / WN, n = t % WN;
+                if constexpr (n == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sa + pl * T_PLANE + (m / 2) * TB + (m & 1) * 512), hi = ds_read_tr16(sa + pl * T_PLANE + (m / 2) * TB + (m & 1) * 512 + hi_off);
+                        af[m][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+                if constexpr (m == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const u32x2 lo = ds_read_tr16(sbb + pl * T_PLANE + (n / 2) * TB + (n & 1) * 512), hi = ds_read_tr16(sbb + pl * T_PLANE + (n / 2) * TB + (n & 1) * 512 + hi_off);
+                        bf[n][pl] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                }
+            }
+        };
+        read_for(std::integral_constant<int, 0>{});
+        read_for(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int idx = I, m = idx / WN, n = idx % WN;
+                read_for(std::integral_constant<int, idx + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][0]), __builtin_bit_cast(h8, bf[n][1]), acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, af[m][1]), __builtin_bit_cast(h8, bf[n][0]), acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (idx < PW8) {
+                    issue_piece(wst, std::integral_constant<int, idx>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, NPAIR>{});
+        if (is_step < 15998) is_step += 2;
+        slot ^= 2;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum += acc[m][n][q];
+    out[(long long)blockIdx.x * 512 + tid] = sum;
+    if (lane == 0) {
+        unsigned long long* stp = stamps + ((long long)blockIdx.x * 8 + wave) * 4;
+        stp[0] = t0; stp[1] = t1; stp[2] = r0; stp[3] = r1;
+    }
+}
+
 __global__ void fill_kernel(unsigned* p, long long n, unsigned seed) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -243,7 +356,7 @@ int main(int argc, char** argv) {
     char* src; float* out; unsigned long long* stamps;
     const long long alloc = 6 * tensor_bytes;
     if (grid % 7 || 16000 / (grid / 7) < nks) { printf("grid must be a multiple of 7 and nks <= 16000 / (grid / 7)\n"); return 1; }
-    CK(hipMalloc(&src, alloc)); CK(hipMalloc(&out, (size_t)grid * 1024)); CK(hipMalloc(&stamps, (size_t)grid * 128));
+    CK(hipMalloc(&src, alloc)); CK(hipMalloc(&out, (size_t)grid * 2048)); CK(hipMalloc(&stamps, (size_t)grid * 256));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (unsigned*)src, alloc / 4, 12345u);
     CK(hipDeviceSynchronize());
     printf("grid %d, %d k-steps per workgroup, %d timed launches per variant; source buffer %.2f GB\n", grid, nks, launches, alloc / 1e9);
@@ -256,5 +369,27 @@ int main(int argc, char** argv) {
     run<9>("16x16x32 + transposed LDS reads", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
     run<11>("16x16x32 + reads + barrier", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
     run<15>("16x16x32 + reads + barrier + DMA, two 64 KiB stages", src, out, stamps, grid, nks, ld, tensor_bytes, launches);
+    {   // eight waves
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int i = 0; i < launches / 2; ++i) hipLaunchKernelGGL(loop8_kernel, dim3(grid), dim3(512), 0, 0, src, out, stamps, nks, ld, tensor_bytes);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(loop8_kernel, dim3(grid), dim3(512), 0, 0, src, out, stamps, nks, ld, tensor_bytes);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> st((size_t)grid * 32);
+        CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> cyc, clk;
+        for (int w = 0; w < grid * 8; ++w) {
+            const double c = (double)(st[w * 4 + 1] - st[w * 4 + 0]), ns = (double)(st[w * 4 + 3] - st[w * 4 + 2]) * 10.0;
+            cyc.push_back(c / nks); clk.push_back(c / ns);
+        }
+        std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+        const double per = ms / launches, flops = 2.0 * 256 * 256 * 16 * 3 * (double)nks * grid * 2.0;
+        printf("%-46s %7.3f ms/launch  %7.1f cyc/k-step (two waves per SIMD: 1536 each)  clock %.2f GHz  %7.0f TFLOP/s\n",
+               "16x16x32, EIGHT waves (128 x 64 each) + DMA", per, cyc[cyc.size() / 2] / 2.0, clk[clk.size() / 2], flops / (per * 1e-3) / 1e12);
+    }
     return 0;
 }
