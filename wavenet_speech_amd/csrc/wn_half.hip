@@ -705,13 +705,17 @@ constexpr int kHCol8 = 128;
 // NT = accumulator tiles per wave along time.  8 -> 256 x 256 workgroup tiles, 64 x 128 per wave, TWO 64 KiB stages with the
 // whole next stage issued at the start of the current one (f16x3: the variant in use); 4 -> 256 x 128 tiles, 64 x 64 per wave,
 // three stages (the first version; a third more LDS read traffic and half again the staging per FLOP: gate 0.407 vs 0.350 ms).
-template <int P, bool BF, int EPI, int NT>
-__global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
-    constexpr int ROWS = 256, COLS = 32 * NT;
+// WR = wave rows: 4 -> eight waves on 256 rows, one workgroup per CU (f16x3); 2 -> four waves on 128 rows and half the LDS, two
+// workgroups per CU: the form of the one-plane modes, whose 32-channel stage is only 24 KiB at 128 x 256.
+template <int P, bool BF, int EPI, int NT, int WR>
+__global__ __launch_bounds__(128 * WR, WR == 4 ? 1 : 2) void hgemm8_kernel(const HGemmArgs a) {
+    constexpr int ROWS = 64 * WR, COLS = 32 * NT, NWAVE = 2 * WR;
     constexpr int A_PLANE = 4 * ROWS * 16, B_PLANE = 4 * COLS * 16;
     constexpr int A_BYTES = P * A_PLANE, B_BYTES = P * B_PLANE, STAGE = A_BYTES + B_BYTES;   // 48 KiB at f16x3, 24 KiB one plane
-    constexpr int D = (163840 / STAGE) > 6 ? 6 : (163840 / STAGE);                            // 3 / 6 stages
-    constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192;                               // 1 KiB pieces per wave and stage
+    constexpr int LDS_BUDGET = WR == 4 ? 163840 : 81920;
+    constexpr int D = (LDS_BUDGET / STAGE) > 6 ? 6 : (LDS_BUDGET / STAGE);
+    constexpr int A_PW = A_BYTES / (1024 * NWAVE), B_PW = B_BYTES / (1024 * NWAVE);           // 1 KiB pieces per wave and stage
+    static_assert(A_PW * 1024 * NWAVE == A_BYTES && B_PW * 1024 * NWAVE == B_BYTES && D >= 2, "piece split / ring depth");
     constexpr int PW = A_PW + B_PW;
     constexpr int INFLIGHT = (D - 2) * PW;
     constexpr int NPAIR = 4 * NT;
@@ -751,11 +755,11 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
     auto issue_piece = [&](char* stage, auto pic) {
         constexpr int PI = decltype(pic)::value;
         if constexpr (PI < A_PW) {
-            const int piece = wave + 8 * PI;                                  // the weight image of a stage is contiguous
+            const int piece = wave + NWAVE * PI;                              // the weight image of a stage is contiguous
             WN_GLDS(a_src + (long long)is_ks * A_BYTES + piece * 1024, lane16, stage + piece * 1024);
         } else {
             constexpr int HC = COLS / 64;                                     // 64-column pieces per (plane, k-group)
-            const int q = wave + 8 * (PI - A_PW);                             // (plane, k-group, column piece)
+            const int q = wave + NWAVE * (PI - A_PW);                         // (plane, k-group, column piece)
             const int hc = q % HC, kg = (q / HC) & 3, p = q / (4 * HC);
             WN_GLDS(b_src + p * is_pstride + (long long)kg * ld * 16 + hc * 1024, lane16,
                     stage + A_BYTES + ((p * 4 + kg) * COLS + 64 * hc) * 16);
@@ -993,13 +997,13 @@ __global__ __launch_bounds__(512, 1) void hgemm8_kernel(const HGemmArgs a) {
     }
 }
 
-template <int P, bool BF, int NT>
+template <int P, bool BF, int NT, int WR = 4>
 static hipError_t launch_h8(int epi, const HGemmArgs& a, unsigned grid, hipStream_t st) {
     switch (epi) {
-        case HEPI_STORE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_STORE, NT>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE, NT>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE, NT>), dim3(grid), dim3(512), 0, st, a); break;
-        case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32, NT>), dim3(grid), dim3(512), 0, st, a); break;
+        case HEPI_STORE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_STORE, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
+        case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
+        case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
+        case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1039,6 +1043,14 @@ hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStr
     HGemmArgs a = a_in;
     static const int dbg = getenv("WN_HGEMM_DBG") ? atoi(getenv("WN_HGEMM_DBG")) : 0;
     a.dbg = dbg;
+    if (MT == 10) {  // hgemm8_kernel, four waves on 128 x 256 tiles, two workgroups per CU (one-plane modes)
+        if (a.L % 16 != 0 || prec == HP_F16X3) return hipErrorInvalidValue;
+        a.tiles_per_row = (a.L + 255) / 256;
+        a.ncol = a.B * a.tiles_per_row;
+        const unsigned g10 = (unsigned)(a.nslab * ((a.ncol + 7) / 8 * 8));
+        if (prec == HP_F16) return launch_h8<1, false, 8, 2>(epi, a, g10, st);
+        return launch_h8<1, true, 8, 2>(epi, a, g10, st);
+    }
     if (MT == 9) {   // hgemm8_kernel, 256 x 256 tiles (f16x3): whole 16-column accumulator tiles, the last tile of a row may be partial
         if (a.L % 16 != 0 || prec != HP_F16X3) return hipErrorInvalidValue;
         a.tiles_per_row = (a.L + 255) / 256;

@@ -92,21 +92,25 @@ struct HPlan {
     //            2.03 vs 2.24, dx 0.381 vs 0.380, res 0.201 vs 0.199, dz 0.317 vs 0.300; step 65.5 vs 66.7 ms -> `prefer` is set
     //            for the gate and skips_sum GEMMs.  The one-plane modes lose with it (cfg5 f16 89.1 vs 84.7 ms/step).
     //            WN_HGEMM16=0: never; =2: wherever the shape allows, every mode (tests); WN_HGEMM16_COLS=128: narrow form.
-    int wide = 0;
-    void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool prefer_k32 = false) {
+    //            One-plane modes: the same code as FOUR waves on 128 x 256 tiles, two workgroups per CU (`quad`; a 32-channel
+    //            stage is only 24 KiB there): every block GEMM whose row count is a multiple of 128 (`allow_quad`).
+    int wide = 0, quad = 0;
+    void init(int out_rows, int planes_, bool long_k = false, int length = 0, bool prefer_k32 = false, bool allow_quad = false) {
         static const int knob = getenv("WN_HGEMM16") ? atoi(getenv("WN_HGEMM16")) : 1;
         static const bool narrow_only = getenv("WN_HGEMM16_COLS") && atoi(getenv("WN_HGEMM16_COLS")) == 128;
         const bool rows_ok = out_rows % 256 == 0 && length > 0;
         const bool fits_wide = rows_ok && planes_ == 2 && length % 16 == 0 && !narrow_only;
         const bool fits_narrow = rows_ok && length % 128 == 0;
-        k32 = ((knob == 2 && (fits_wide || fits_narrow)) || (knob == 1 && prefer_k32 && planes_ == 2 && (fits_wide || fits_narrow))) ? 1 : 0;
-        wide = (k32 && fits_wide) ? 1 : 0;
-        MT = (k32 || (long_k && out_rows > 128)) ? 4 : 2;
+        quad = (knob != 0 && knob != 2 && allow_quad && planes_ == 1 && out_rows % 128 == 0 && length > 0 && length % 16 == 0) ? 1 : 0;
+        k32 = (quad || (knob == 2 && (fits_wide || fits_narrow)) ||
+               (knob == 1 && prefer_k32 && planes_ == 2 && (fits_wide || fits_narrow))) ? 1 : 0;
+        wide = (k32 && !quad && fits_wide) ? 1 : 0;
+        MT = quad ? 2 : ((k32 || (long_k && out_rows > 128)) ? 4 : 2);
         rows = 64 * MT;
         planes = planes_;
     }
-    int kernel() const { return k32 ? (wide ? 9 : 8) : MT; } // what launch_hgemm is told
-    int wave_rows() const { return k32 ? 4 : 2; }            // wave rows of the workgroup (each wave owns rows / wave_rows rows)
+    int kernel() const { return quad ? 10 : (k32 ? (wide ? 9 : 8) : MT); } // what launch_hgemm is told
+    int wave_rows() const { return (k32 && !quad) ? 4 : 2; } // wave rows of the workgroup (each wave owns rows / wave_rows rows)
     bool add_slab(int nseg_used, int row0) {
         if (nslab >= kHMaxSlab) return false;
         const int s = nslab++;
@@ -134,7 +138,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     {   // FA: [a ; g] interleaved in 32-channel tile pairs; K = k taps of x
         HPlan& g = p.fa;
-        g.init(2 * Co, P, false, s->length, true);
+        g.init(2 * Co, P, false, s->length, true, true);
         g.nseg = k;
         for (int j = 0; j < k; ++j) g.seg_nks[j] = cp32(Ci) / 16;
         const int ch_per_slab = g.rows / 2;
@@ -142,7 +146,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // FR: r rows contract [z ; x]
         HPlan& g = p.fr;
-        g.init(Co, P, false, s->length, false);
+        g.init(Co, P, false, s->length, false, true);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Co) / 16;
         g.seg_nks[1] = cp32(Ci) / 16;
@@ -157,7 +161,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KA: dz rows (z channels) contract [dskip ; dr]
         HPlan& g = p.ka;
-        g.init(Co, P, false, s->length, false);
+        g.init(Co, P, false, s->length, false, true);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Ms) / 16;
         g.seg_nks[1] = cp32(Co) / 16;
@@ -165,7 +169,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KB: dx rows (input channels) contract [da_0; dg_0; ...; dr]
         HPlan& g = p.kb;
-        g.init(Ci, P, false, s->length, false);
+        g.init(Ci, P, false, s->length, false, true);
         g.nseg = 2 * k + 1;
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
