@@ -31,7 +31,7 @@ for path in sys.argv[1:]:
             segs.append((n, len(mf), len(drains)))
         # the f16x3 wgrad ring and the 256 x 256 f16x3 GEMM have two 64 KiB stages: their wait at the barrier is vmcnt(0) by design (the next stage is issued
         # AFTER the barrier); everywhere else a prefetch must stay in flight across the barrier
-        two_stage = "hwgrad_kernel<2," in name or re.search(r"hgemm8_kernel<2, \w+, \d, 8>", name) is not None
+        two_stage = "hwgrad_kernel<2," in name or re.search(r"hgemm8_kernel<2, \w+, \d, 8, 4>", name) is not None
         ok = bool(segs) and all((n > 0 or (two_stage and n == 0)) and d == 0 for n, _, d in segs)
         bad += 0 if ok else 1
         n, mf, drains = (segs[0][0], [0] * sum(x[1] for x in segs), [0] * sum(x[2] for x in segs)) if segs else (-1, [], [])
