@@ -66,7 +66,8 @@ def test_hip_ctc_known_answer_on_the_device():
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,B,C,Tn,lmax,repeats", [(1, 3, 5, 12, 4, False), (2, 2, 7, 30, 9, False), (3, 2, 5, 9, 4, True),
                                                       (4, 1, 4, 3, 3, False), (6, 2, 3, 20, 10, True), (7, 4, 5, 200, 40, False),
-                                                      (8, 2, 64, 70, 33, False), (9, 3, 5, 130, 64, False)])
+                                                      (8, 2, 64, 70, 33, False), (9, 3, 5, 130, 64, False),
+                                                      (10, 1, 2, 1, 1, False), (12, 2, 3, 2, 1, True), (13, 1, 5, 1, 3, False)])
 def test_hip_ctc_matches_the_oracle(seed, B, C, Tn, lmax, repeats):
     acts, labels, lens = _random_case(seed, B, C, Tn, lmax, repeats)
     acts = acts.astype(np.float32).astype(np.float64)                   # the device reads fp32 activations

@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 1, 1, True, 300), (2, 32, 32, 2, 1, True, 300), (1, 24, 40, 3, 5, False, 130),
                                   (3, 1, 48, 3, 1, True, 77), (2, 256, 256, 1, 1, True, 512), (1, 64, 5, 1, 1, True, 1000),
-                                  (2, 40, 72, 2, 300, True, 260)])
+                                  (2, 40, 72, 2, 300, True, 260), (1, 8, 8, 2, 1, True, 1), (2, 16, 24, 3, 2, False, 7)])
 @pytest.mark.parametrize("precision", ["f16x3", "f16", "bf16"])
 def test_half_conv_matches_the_oracle(case, precision):
     B, Ci, Co, k, d, causal, L = case

@@ -142,6 +142,15 @@ def test_hip_generator_random_stages_and_full_size():
     assert int(diff.max()) <= 1 and int((diff != 0).sum()) <= 3, (int(diff.max()), int((diff != 0).sum()))
     kmers = S.kmer_indices(bases, 3)[:, :16000]
     assert float((pico - means.double()[kmers]).abs().max()) < 6.5 * float(stdvs.max())   # every sample within 6.5 sigma
+    # smallest and ragged shapes: one read of two samples (a span of zero would divide by zero, as in the reference), a length
+    # that is not a multiple of the upsampling or of the kernel's tile, no one-hot
+    for B_, L_ in ((1, 2), (3, 7), (2, 257)):
+        lv, oh_, bs = S.gaussian_kmer_signal(B_, L_, generator=torch.Generator(device=dev).manual_seed(L_), device=dev)
+        assert lv.shape == (B_, L_) and oh_.shape == (B_, 256, L_) and int(lv.min()) >= 0 and int(lv.max()) <= 255
+        assert torch.equal(oh_.argmax(1), lv)
+        _, _, pc = S.hip_signal(bs, L_, 256, 3, None, seed=1, want_one_hot=False)
+        lv2, _, _ = S.hip_signal(bs, L_, 256, 3, None, picoamps=pc, want_one_hot=False)
+        assert int((lv2 - S.quantize(pc, 256).clamp(0, 255)).abs().max()) <= 1
 
 
 @pytest.mark.gpu
