@@ -183,13 +183,17 @@ def test_fp16_overflow_is_loud():
     with torch.no_grad():
         with pytest.raises(RuntimeError, match="overflow"):
             net(x)
-    net(x)                                               # training call: returns, the flag travels asynchronously
+    # training call: the flag travels asynchronously; whichever library call first finds it landed raises (that can be a later
+    # kernel launch of the same model call -- the output-stack convs poll too), at the latest check_device_flags()
     with pytest.raises(RuntimeError, match="overflow"):
+        net(x)
         W.check_fp16_overflow()
-    net(x)
-    torch.cuda.synchronize()
-    with pytest.raises(RuntimeError, match="overflow"):  # ... and the next call into the stack reports it
-        net(torch.randn(1, c, 100, device=DEV))
+    for _ in range(4):                                   # flags of later launches of the same call may still be in flight
+        try:
+            W.check_fp16_overflow()
+            break
+        except RuntimeError:
+            pass
     W.check_fp16_overflow()                              # nothing left pending
     W.set_precision(net, "bf16")
     assert bool(torch.isfinite(net(x)).all())

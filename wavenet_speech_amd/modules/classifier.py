@@ -5,7 +5,7 @@ same non-causal residual stack); consumes WaveNet's output distribution in the j
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, StackState, run_stack, pointwise_precision
+from .block import ResidualBlock, StackState, run_stack, pointwise_precision, head_precision
 from .pointwise import run_sequential
 
 
@@ -42,7 +42,7 @@ class WaveNetClassifier(nn.Module):
         out = self.mean_pool(seq)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
                               [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
-        logit_seq = run_sequential(self.output_block, skips_sum, pointwise_precision(self.stack_state.precision))
+        logit_seq = run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)

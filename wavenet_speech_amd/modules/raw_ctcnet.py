@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, StackState, run_stack, pointwise_precision
+from .block import ResidualBlock, StackState, run_stack, pointwise_precision, head_precision
 from .pointwise import run_sequential
 
 
@@ -62,7 +62,7 @@ class RawCTCNet(nn.Module):
             out = out + run_sequential(self.positions_conv1x1, steps, pointwise_precision(self.stack_state.precision))
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
                               [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
-        logit_seq = run_sequential(self.output_block, skips_sum, pointwise_precision(self.stack_state.precision))
+        logit_seq = run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)

@@ -8,7 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as HF
-from .block import ResidualBlock, StackState, run_stack, pointwise_precision
+from .block import ResidualBlock, StackState, run_stack, pointwise_precision, head_precision
 from .conv_ops import CausalConv1d
 from .pointwise import run_sequential
 
@@ -59,7 +59,7 @@ class WaveNet(nn.Module):
 
     def _after_entry(self, out):
         skips_sum = run_stack(out, self.convolutions, self.bottlenecks, self.stack_state)
-        output_seq = run_sequential(self.output_stack, skips_sum, pointwise_precision(self.stack_state.precision))
+        output_seq = run_sequential(self.output_stack, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
             return output_seq
         return F.softmax(output_seq, dim=1)  # the reference's reshape_in/softmax/reshape_out == softmax over channels
