@@ -112,13 +112,19 @@ struct HLoadArgs {
 
 // ---- weight gradients ------------------------------------------------------------------------------------------
 struct HWgradPair {
-    const char* A; const char* Bm;      // half series
-    long long a_ustride, a_pstride, b_ustride, b_pstride;
-    int a_groups, b_groups;             // channel groups (padded channels / 8) the operands really have
-    int off;                            // column offset on the B side
-    int mt, nt;                         // 256-row / 256-column workgroup tiles
+    // The 256-channel A tile and B tile of a workgroup are each staged as two HALVES of 128 channels.  An ordinary pair reads
+    // both halves from one tensor (half 1 = the next 16 channel groups: a_gb = {0, 16}); a COMPOSITE pair (all channel counts
+    // <= 128: wn_half_api.hip) takes them from two tensors -- A = [da ; dg], B = [x(t + off_0) ; x(t + off_1)] -- so that one
+    // 256 x 256 accumulator tile holds up to four 128 x 128 gradient matrices instead of one padded to 256 x 256.
+    const char* A[2]; const char* Bm[2];    // half series, per half
+    long long a_ustride[2], a_pstride[2], b_ustride[2], b_pstride[2];
+    int a_groups[2], b_groups[2];           // channel groups (padded channels / 8) the operands really have
+    int a_gb[2], b_gb[2];                   // first channel group of the half inside its tensor (before the tile's 32 tm / 32 tn)
+    int off[2];                             // column offset on the B side, per half
+    int quad_mask;                          // bit (2 * A half + B half): that 128 x 128 quadrant is wanted (its wave computes and stores it)
+    int mt, nt;                             // 256-row / 256-column workgroup tiles
     int tile0;
-    long long slab_off;                 // float offset of this pair's [Mp x Np] block inside a split's slab
+    long long slab_off;                     // float offset of this pair's [Mp x Np] block inside a split's slab
     int Mp, Np;
     int rowsum, rs_off;
 };

@@ -25,104 +25,10 @@
 #include <utility>
 
 #include "wn_half.h"
+#include "wn_half_dev.h"
 
 namespace wn {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// LDS-DMA from inline asm (M0 = LDS destination base, saved / set / restored inside the statement), counted by hand with the
-// loop's `s_waitcnt vmcnt(N)`: hipcc then knows of no pending LDS write and cannot decide to drain the ring in front of an LDS
-// read (it did exactly that in hwgrad_kernel with the builtin; wn_half_wgrad.hip).
-// Address form: wave-uniform 64-bit base in an SGPR pair + a 32-bit per-lane byte offset (one VGPR that never changes), so a
-// piece costs no vector address arithmetic and no address registers.
-__device__ __forceinline__ void glds16(const char* ubase, unsigned lane_off, const char* lds_dst) {
-    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(ubase), "s"(dst) : "memory");
-}
-#define WN_GLDS(ub, lo, lp) glds16((ub), (lo), (lp))
-
-// ---------------------------------------------------------------------------------------------------------------
-// value <-> storage helpers
-// ---------------------------------------------------------------------------------------------------------------
-template <bool BF> struct HT;
-template <> struct HT<false> { typedef _Float16 t; typedef h4 v4; typedef h8 v8; };
-template <> struct HT<true> { typedef __bf16 t; typedef b4 v4; typedef b8 v8; };
-
-// The lo plane must be the remainder against EXACTLY the bits stored in the hi plane.  hipcc is free to convert the same
-// fp32 value twice (a packed v_cvt_pk_f16_f32 for the store, a scalar v_cvt_f16_f32 for the subtraction), and on gfx950 the
-// two disagree on exact ties -- measured: 4 of 153 600 elements came out with lo = -half-ulp instead of +half-ulp, an
-// error of one fp16 ulp.  Passing the packed hi through an empty asm makes it opaque: the remainder is then computed from
-// the register that is stored.
-template <typename V>
-__device__ __forceinline__ V pin(V v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
-// four consecutive channels of one time step -> 8 bytes in plane 0 (and the fp16 remainder in plane 1)
-template <int P, bool BF, bool CHK = true>   // CHK = false: the values cannot exceed fp16's range (tanh, sigmoid and their product)
-__device__ __forceinline__ void store4(char* p, long long pstride, const float (&v)[4], unsigned& ovf) {
-    typedef typename HT<BF>::t T;
-    typedef typename HT<BF>::v4 V4;
-    V4 hi;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) hi[q] = (T)v[q];
-    if constexpr (P == 2) hi = pin(hi);
-    *reinterpret_cast<V4*>(p) = hi;
-    if constexpr (!BF && CHK) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ovf |= (__builtin_fabsf(v[q]) > 65504.0f) ? 1u : 0u;
-    }
-    if constexpr (P == 2) {
-        V4 lo;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lo[q] = (T)(v[q] - (float)hi[q]);
-        *reinterpret_cast<V4*>(p + pstride) = lo;
-    }
-}
-
-template <int P, bool BF>
-__device__ __forceinline__ void load4(const char* p, long long pstride, float (&v)[4]) {
-    typedef typename HT<BF>::v4 V4;
-    const V4 hi = *reinterpret_cast<const V4*>(p);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (float)hi[q];
-    if constexpr (P == 2) {
-        const V4 lo = *reinterpret_cast<const V4*>(p + pstride);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += (float)lo[q];
-    }
-}
-
-__device__ __forceinline__ float h_sigmoid(float x) {
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * x);
-    return __builtin_amdgcn_rcpf(1.0f + e);
-}
-__device__ __forceinline__ float h_tanh(float x) {   // same formulation as the fp32 kernel (wn_gemm.hip): |err| <= 2e-7
-    const float ax = __builtin_fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * ax);
-    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    const float x2 = x * x;
-    const float small = ax * (1.0f + x2 * (-0.333333333f + x2 * (0.133333333f + x2 * -0.0539682540f)));
-    return __builtin_copysignf(ax < 0.125f ? small : big, x);
-}
-
-// backward of the gate from what the forward pass keeps: z = tanh(a) sigmoid(g) and s = sigmoid(g).  The tanh is not stored
-// (one tensor less to write in the forward gate launch and to keep until backward): t = z / s.
-//     da = dz s (1 - t^2) = dz (s - z t)         dg = dz t s (1 - s) = dz z (1 - s)
-// s = 0 (sigmoid underflow) has z = 0 and both gradients 0.  An error in the recovered t enters da multiplied by z <= s.
-__device__ __forceinline__ void dgate(float dz, float z, float s, float& da, float& dg) {
-    const float t = s > 0.0f ? z / s : 0.0f;
-    da = dz * (s - z * t);
-    dg = dz * z * (1.0f - s);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // dense fp32 [B][C][L]  ->  half series

@@ -527,8 +527,28 @@ int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* pa
 
 // ---- weight gradients ------------------------------------------------------------------------------------------------------
 namespace {
-struct HPairSpec { const void* A; int a_rows; const void* Bm; int b_rows; int off; int rowsum; float post;
-                   float* w; int sm, sn; float* b0; float* b1; };
+// One workgroup tile of hwgrad_kernel is 256 x 256 (A rows x B rows) and is staged as two 128-channel halves per operand.
+// A pair spec names the tensors behind the halves and the destinations of the 128 x 128 quadrants (composite pairs), or one
+// tensor per operand and one destination covering the whole matrix (ordinary pairs).
+struct HHalf { const void* p; int rows; int off; };
+struct HQuad { int ah, bh; float post; float* w; int sm, sn; float* b0; float* b1; };   // b0 / b1: destinations of the row sums of A half ah
+struct HPairSpec {
+    HHalf a[2], b[2];
+    bool composite;
+    int rowsum;
+    std::vector<HQuad> q;
+};
+
+HPairSpec plain_pair(const void* A, int a_rows, const void* Bm, int b_rows, int off, int rowsum, float post, float* w, int sm, int sn,
+                     float* b0, float* b1) {
+    HPairSpec s;
+    s.a[0] = s.a[1] = HHalf{A, a_rows, 0};
+    s.b[0] = s.b[1] = HHalf{Bm, b_rows, off};
+    s.composite = false;
+    s.rowsum = rowsum;
+    s.q.push_back(HQuad{0, 0, post, w, sm, sn, rowsum ? b0 : nullptr, rowsum ? b1 : nullptr});
+    return s;
+}
 
 struct HWPlan {
     int npair = 0, ntile_total = 0, nsplit = 1;
@@ -536,6 +556,7 @@ struct HWPlan {
     long long slab_off[kMaxPair];
     long long slab_floats = 0;
     int rs_floats = 0;
+    bool composite = false;
     void add(int M, int N) {
         const int T = 256, i = npair++;
         mt[i] = cdiv(M, T); nt[i] = cdiv(N, T);
@@ -545,7 +566,10 @@ struct HWPlan {
         rs_off[i] = rs_floats; rs_floats += Mp[i];
     }
     void finish(int nstep) {
-        nsplit = std::max(1, 512 / std::max(1, ntile_total));
+        // ordinary pairs: two rounds of workgroups on the 256 CUs.  Composite pairs (2-3 tiles per block) are short: every
+        // workgroup ends with a 256 KiB partial tile that the reduction re-reads, so ONE round and half the partial slabs
+        const int target = composite ? 256 : 512;
+        nsplit = std::max(1, target / std::max(1, ntile_total));
         nsplit = std::min(nsplit, std::max(1, nstep / 8));      // at least a few k-steps per split
         if (nsplit >= 16) nsplit = nsplit / 8 * 8;
     }
@@ -553,19 +577,55 @@ struct HWPlan {
     size_t bytes() const { return (size_t)nsplit * (size_t)(slab_floats + rs_floats) * 4; }
 };
 
+bool composite_wgrad(int ci, int co, int ms) {
+    static const bool off = getenv("WN_HWGRAD_COMPOSITE") && atoi(getenv("WN_HWGRAD_COMPOSITE")) == 0;
+    return !off && cp32(ci) <= 128 && cp32(co) <= 128 && cp32(ms) <= 128;
+}
+
 std::vector<HPairSpec> hblock_pairs(const wn_block_shape* s, const int* off, const void* x, const void* z, const void* da,
                                     const void* dg, const void* dr, const void* dskip, const wn_block_params* g) {
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     const float inv_rs = 1.0f / kResidualScale;
     std::vector<HPairSpec> ps;
-    for (int j = 0; j < k; ++j) {
-        ps.push_back({da, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_tanh + j : nullptr, Ci * k, k, g ? g->b_tanh : nullptr, nullptr});
-        ps.push_back({dg, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_sigmoid + j : nullptr, Ci * k, k, g ? g->b_sigmoid : nullptr, nullptr});
+    if (composite_wgrad(Ci, Co, Ms)) {
+        // [da ; dg] x [x(t + off_j) ; x(t + off_j+1)]: the four tap gradients of two taps in one tile
+        for (int j = 0; j < k; j += 2) {
+            const bool two = j + 1 < k;
+            HPairSpec p;
+            p.composite = true;
+            p.rowsum = j == 0;
+            p.a[0] = HHalf{da, Co, 0}; p.a[1] = HHalf{dg, Co, 0};
+            p.b[0] = HHalf{x, Ci, off[j]}; p.b[1] = HHalf{x, Ci, two ? off[j + 1] : off[j]};
+            p.q.push_back(HQuad{0, 0, inv_rs, g ? g->w_tanh + j : nullptr, Ci * k, k, (g && j == 0) ? g->b_tanh : nullptr, nullptr});
+            p.q.push_back(HQuad{1, 0, inv_rs, g ? g->w_sigmoid + j : nullptr, Ci * k, k, (g && j == 0) ? g->b_sigmoid : nullptr, nullptr});
+            if (two) {
+                p.q.push_back(HQuad{0, 1, inv_rs, g ? g->w_tanh + j + 1 : nullptr, Ci * k, k, nullptr, nullptr});
+                p.q.push_back(HQuad{1, 1, inv_rs, g ? g->w_sigmoid + j + 1 : nullptr, Ci * k, k, nullptr, nullptr});
+            }
+            ps.push_back(p);
+        }
+        // [dskip ; dr] x [z ; x]: skip, residual and projection gradients (the dskip x quadrant is not computed)
+        HPairSpec p;
+        p.composite = true;
+        p.rowsum = 1;
+        p.a[0] = HHalf{dskip, Ms, 0}; p.a[1] = dr ? HHalf{dr, Co, 0} : p.a[0];
+        p.b[0] = HHalf{z, Co, 0}; p.b[1] = dr ? HHalf{x, Ci, 0} : p.b[0];
+        p.q.push_back(HQuad{0, 0, 1.0f, g ? g->w_skip : nullptr, Co, 1, g ? g->b_skip : nullptr, nullptr});
+        if (dr) {
+            p.q.push_back(HQuad{1, 0, 1.0f, g ? g->w_res : nullptr, Co, 1, g ? g->b_res : nullptr, g ? g->b_proj : nullptr});
+            p.q.push_back(HQuad{1, 1, inv_rs, g ? g->w_proj : nullptr, Ci, 1, nullptr, nullptr});
+        }
+        ps.push_back(p);
+        return ps;
     }
-    ps.push_back({dskip, Ms, z, Co, 0, 1, 1.0f, g ? g->w_skip : nullptr, Co, 1, g ? g->b_skip : nullptr, nullptr});
+    for (int j = 0; j < k; ++j) {
+        ps.push_back(plain_pair(da, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_tanh + j : nullptr, Ci * k, k, g ? g->b_tanh : nullptr, nullptr));
+        ps.push_back(plain_pair(dg, Co, x, Ci, off[j], j == 0, inv_rs, g ? g->w_sigmoid + j : nullptr, Ci * k, k, g ? g->b_sigmoid : nullptr, nullptr));
+    }
+    ps.push_back(plain_pair(dskip, Ms, z, Co, 0, 1, 1.0f, g ? g->w_skip : nullptr, Co, 1, g ? g->b_skip : nullptr, nullptr));
     if (dr) {
-        ps.push_back({dr, Co, z, Co, 0, 1, 1.0f, g ? g->w_res : nullptr, Co, 1, g ? g->b_res : nullptr, g ? g->b_proj : nullptr});
-        ps.push_back({dr, Co, x, Ci, 0, 0, inv_rs, g ? g->w_proj : nullptr, Ci, 1, nullptr, nullptr});
+        ps.push_back(plain_pair(dr, Co, z, Co, 0, 1, 1.0f, g ? g->w_res : nullptr, Co, 1, g ? g->b_res : nullptr, g ? g->b_proj : nullptr));
+        ps.push_back(plain_pair(dr, Co, x, Ci, 0, 0, inv_rs, g ? g->w_proj : nullptr, Ci, 1, nullptr, nullptr));
     }
     return ps;
 }
@@ -573,7 +633,13 @@ std::vector<HPairSpec> hblock_pairs(const wn_block_shape* s, const int* off, con
 int run_hwgrad(const std::vector<HPairSpec>& ps, int prec, int B, int L, int ld, int halo, const float* dyn_inv, void* workspace,
                size_t workspace_bytes, bool dry, size_t* need, hipStream_t st) {
     HWPlan wp;
-    for (const HPairSpec& p : ps) wp.add(p.a_rows, p.b_rows);
+    int ndst = 0;
+    for (const HPairSpec& p : ps) {
+        if (p.composite) { wp.add(256, 256); wp.composite = true; }
+        else wp.add(p.a[0].rows, p.b[0].rows);
+        ndst += (int)p.q.size();
+    }
+    if (wp.npair > kMaxPair || ndst > kMaxPair) return WN_ERR_UNSUPPORTED;
     const int spr = cdiv(L, 32);                      // stages of 32 time steps per utterance (hwgrad_kernel)
     wp.finish(B * spr);
     if (need) *need = wp.bytes();
@@ -586,28 +652,39 @@ int run_hwgrad(const std::vector<HPairSpec>& ps, int prec, int B, int L, int ld,
     ReduceArgs r;
     std::memset(&r, 0, sizeof(r));
     double flops = 0;
+    int nd = 0;
     for (int i = 0; i < wp.npair; ++i) {
         HWgradPair& q = a.pair[i];
-        const HView va = view(ps[i].A, ps[i].a_rows, ld, P), vb = view(ps[i].Bm, ps[i].b_rows, ld, P);
-        // the kernel stages whole 256-channel tiles: the operands' padded channel counts must cover them
-        q.a_groups = va.cp / 8; q.b_groups = vb.cp / 8;
-        q.A = va.base; q.Bm = vb.base; q.a_ustride = va.ustride; q.a_pstride = va.pstride; q.b_ustride = vb.ustride; q.b_pstride = vb.pstride;
-        q.off = ps[i].off; q.mt = wp.mt[i]; q.nt = wp.nt[i]; q.tile0 = wp.tile0[i];
+        const HPairSpec& p = ps[i];
+        for (int hf = 0; hf < 2; ++hf) {
+            // the kernel stages whole 128-channel halves: the operands' padded channel counts (multiples of 32) bound the groups read
+            const HView va = view(p.a[hf].p, p.a[hf].rows, ld, P), vb = view(p.b[hf].p, p.b[hf].rows, ld, P);
+            q.A[hf] = va.base; q.a_ustride[hf] = va.ustride; q.a_pstride[hf] = va.pstride; q.a_groups[hf] = va.cp / 8;
+            q.Bm[hf] = vb.base; q.b_ustride[hf] = vb.ustride; q.b_pstride[hf] = vb.pstride; q.b_groups[hf] = vb.cp / 8;
+            q.a_gb[hf] = q.b_gb[hf] = p.composite ? 0 : 16 * hf;
+            q.off[hf] = p.b[hf].off;
+        }
+        q.mt = wp.mt[i]; q.nt = wp.nt[i]; q.tile0 = wp.tile0[i];
         q.slab_off = wp.slab_off[i]; q.Mp = wp.Mp[i]; q.Np = wp.Np[i];
-        q.rowsum = ps[i].rowsum; q.rs_off = wp.rs_off[i];
-        ReduceDst& d = r.d[i];
-        d.w = ps[i].w; d.M = ps[i].a_rows; d.N = ps[i].b_rows; d.sm = ps[i].sm; d.sn = ps[i].sn;
-        d.slab_off = wp.slab_off[i]; d.Np = wp.Np[i];
-        d.b0 = ps[i].rowsum ? ps[i].b0 : nullptr; d.b1 = ps[i].rowsum ? ps[i].b1 : nullptr; d.rs_off = wp.rs_off[i];
-        d.post = ps[i].post;
-        flops += 2.0 * ps[i].a_rows * (double)ps[i].b_rows * (double)B * L;
+        q.rowsum = p.rowsum; q.rs_off = wp.rs_off[i];
+        q.quad_mask = p.composite ? 0 : 15;
+        for (const HQuad& qd : p.q) {
+            if (p.composite) q.quad_mask |= 1 << (2 * qd.ah + qd.bh);
+            ReduceDst& d = r.d[nd++];
+            d.w = qd.w; d.M = p.a[qd.ah].rows; d.N = p.b[qd.bh].rows; d.sm = qd.sm; d.sn = qd.sn;
+            d.slab_off = wp.slab_off[i] + (p.composite ? (long long)(128 * qd.ah) * wp.Np[i] + 128 * qd.bh : 0);
+            d.Np = wp.Np[i];
+            d.b0 = qd.b0; d.b1 = qd.b1; d.rs_off = wp.rs_off[i] + (p.composite ? 128 * qd.ah : 0);
+            d.post = qd.post;
+            flops += 2.0 * d.M * (double)d.N * (double)B * L;
+        }
     }
     a.npair = wp.npair; a.ntile_total = wp.ntile_total; a.nsplit = wp.nsplit; a.xcd_map = wp.xcd_map() ? 1 : 0;
     a.B = B; a.L = L; a.ld = ld; a.halo = halo; a.steps_per_row = spr; a.nstep = B * spr;
     a.slab = reinterpret_cast<float*>(workspace);
     a.rowsum = a.slab + (size_t)wp.nsplit * wp.slab_floats;
     a.slab_floats = wp.slab_floats; a.rs_floats = wp.rs_floats;
-    r.npair = wp.npair; r.nsplit = wp.nsplit; r.slab = a.slab; r.rowsum = a.rowsum;
+    r.npair = nd; r.nsplit = wp.nsplit; r.slab = a.slab; r.rowsum = a.rowsum;
     r.slab_floats = wp.slab_floats; r.rs_floats = wp.rs_floats; r.dyn_inv = dyn_inv;
     {
         wn::ProfScopeShared prof(KC_HWGRAD, flops, st);
@@ -765,8 +842,8 @@ std::vector<HPairSpec> hconv_pairs(const wn_conv_shape* s, const int* off, const
     std::vector<HPairSpec> ps;
     const int Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
     for (int j = 0; j < k; ++j)
-        ps.push_back({dy, Co, x, Ci, off[j], (j == 0 && db) ? 1 : 0, 1.0f / input_scale, dw ? dw + j : nullptr, Ci * k, k,
-                      (j == 0) ? db : nullptr, nullptr});
+        ps.push_back(plain_pair(dy, Co, x, Ci, off[j], (j == 0 && db) ? 1 : 0, 1.0f / input_scale, dw ? dw + j : nullptr, Ci * k, k,
+                                (j == 0) ? db : nullptr, nullptr));
     return ps;
 }
 }  // namespace

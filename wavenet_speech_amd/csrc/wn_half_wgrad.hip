@@ -114,30 +114,39 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const int su_g = (lane >> 3) & 1;
     const int su_t = 8 * (2 * (lane >> 5) + ((lane >> 2) & 1)) + 4 * ((lane >> 4) & 1) + (lane & 3);
     const unsigned lane_src = (unsigned)((su_g * a.ld + su_t) * 16);   // < 2 groups x ld x 16 B: fits 32 bits
-    // piece j of a plane = channel groups 2j, 2j+1 = operand tile j; wave w stages pieces w, w+4, w+8, w+12 of every
-    // (operand, plane): PW pieces per wave and stage, in the order (jj, plane, A then B).
+    // piece j of a plane = operand tile j = two channel groups; pieces 0..7 are the first HALF of the 256-channel tile, 8..15 the
+    // second (another tensor in a composite pair, wn_half.h).  Wave w stages pieces w, w+4, w+8, w+12 of every (operand,
+    // plane): PW pieces per wave and stage, in the order (jj, plane, A then B); jj >> 1 = the half, a compile-time constant.
+    // A tile may reach past the operand's channels (outputs of those rows / columns are never read): stay inside the tensor
+    // by re-reading its last two groups.
+    long long goff_a[4], goff_b[4];                 // byte offset of this wave's piece jj inside its half's tensor (loop-invariant)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int hf = jj >> 1, pc = wave + 4 * (jj & 1);
+        goff_a[jj] = (long long)min(tm * (CH / 8) + pr.a_gb[hf] + 2 * pc, pr.a_groups[hf] - 2) * a.ld * 16;
+        goff_b[jj] = (long long)min(tn * (CH / 8) + pr.b_gb[hf] + 2 * pc, pr.b_groups[hf] - 2) * a.ld * 16;
+    }
     int is_step = s_begin;
-    const char* is_a = nullptr;
-    const char* is_b = nullptr;
+    const char* is_a[2] = {nullptr, nullptr};
+    const char* is_b[2] = {nullptr, nullptr};
     auto stage_sources = [&]() {                    // wave-uniform source bases of the stage to issue next
         const int sb = is_step / a.steps_per_row;
         const int st = (is_step - sb * a.steps_per_row) * KT;
-        is_a = pr.A + (long long)sb * pr.a_ustride + ((long long)a.halo + st) * 16;
-        is_b = pr.Bm + (long long)sb * pr.b_ustride + ((long long)a.halo + st + pr.off) * 16;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            is_a[hf] = pr.A[hf] + (long long)sb * pr.a_ustride[hf] + ((long long)a.halo + st) * 16;
+            is_b[hf] = pr.Bm[hf] + (long long)sb * pr.b_ustride[hf] + ((long long)a.halo + st + pr.off[hf]) * 16;
+        }
     };
     auto issue_piece = [&](char* stage, auto pic) {      // stage = LDS image of the stage being filled
         constexpr int PI = decltype(pic)::value;
-        constexpr int jj = PI / (2 * P), pl = (PI % (2 * P)) / 2;
+        constexpr int jj = PI / (2 * P), pl = (PI % (2 * P)) / 2, hf = jj >> 1;
         constexpr bool isB = (PI & 1) != 0;
         const int piece = wave + 4 * jj;
-        // a tile may reach past the operand's channels (outputs of those rows/columns are never read): stay inside the
-        // tensor by re-reading its last two groups
         if constexpr (!isB) {
-            const int ga = min(tm * (CH / 8) + 2 * piece, pr.a_groups - 2);
-            WN_GLDS(is_a + pl * pr.a_pstride + (long long)ga * a.ld * 16, lane_src, stage + pl * T_PLANE + piece * 1024);
+            WN_GLDS(is_a[hf] + pl * pr.a_pstride[hf] + goff_a[jj], lane_src, stage + pl * T_PLANE + piece * 1024);
         } else {
-            const int gb = min(tn * (CH / 8) + 2 * piece, pr.b_groups - 2);
-            WN_GLDS(is_b + pl * pr.b_pstride + (long long)gb * a.ld * 16, lane_src, stage + A_BYTES + pl * T_PLANE + piece * 1024);
+            WN_GLDS(is_b[hf] + pl * pr.b_pstride[hf] + goff_b[jj], lane_src, stage + A_BYTES + pl * T_PLANE + piece * 1024);
         }
     };
     auto issue_advance = [&]() { if (is_step + 1 < s_end) ++is_step; };   // past the end the last stage is staged again
@@ -166,6 +175,10 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     const unsigned rd = (unsigned)((32 * (kb >> 1) + 8 * (pp >> 1) + 4 * (kb & 1) + q4) * 16 + 8 * (pp & 1));
     constexpr int hi_off = 256;                    // steps + 4: unit index + 16
     const bool do_rs = pr.rowsum != 0;
+    // wave (wm, wn) owns quadrant (A half wm, B half wn) of the tile: a composite pair may not want all four.  An unwanted
+    // quadrant is still computed (its wave stages, waits and sums bias rows with the others; skipping its MFMAs would not
+    // shorten the workgroup, and a branch around the tile loop made hipcc spill the accumulators) but never stored.
+    const bool wanted = (pr.quad_mask >> (2 * wm + wn)) & 1;
 
     if (nks > 0) {
 #pragma unroll
@@ -249,15 +262,17 @@ __global__ __launch_bounds__(256, 1) void hwgrad_kernel(const HWgradArgs a) {
     // ---- write this split's partial tile -----------------------------------------------------------------------------
     // C/D layout of v_mfma_f32_16x16x32: column = lane & 15, rows 4 (lane >> 4) + q
     float* out = a.slab + (long long)split * a.slab_floats + pr.slab_off;
+    if (wanted) {
 #pragma unroll
-    for (int m = 0; m < WT; ++m)
+        for (int m = 0; m < WT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = tm * CH + wm * 16 * WT + 16 * m + 4 * kb + q;
-            float* prow = out + (long long)row * pr.Np + tn * CH + wn * 16 * WT + (lane & 15);
+            for (int q = 0; q < 4; ++q) {
+                const int row = tm * CH + wm * 16 * WT + 16 * m + 4 * kb + q;
+                float* prow = out + (long long)row * pr.Np + tn * CH + wn * 16 * WT + (lane & 15);
 #pragma unroll
-            for (int n = 0; n < WT; ++n) prow[16 * n] = acc[m][n][q];
-        }
+                for (int n = 0; n < WT; ++n) prow[16 * n] = acc[m][n][q];
+            }
+    }
     if (do_rs && tn == 0) {
 #pragma unroll
         for (int mm = 0; mm < WT / 2; ++mm) {
