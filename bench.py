@@ -83,6 +83,10 @@ def parse():
                          "amplify the residual stream by ~2^30, beyond any 16-bit format)")
     ap.add_argument("--no-second-line", action="store_true",
                     help="cfg3/f32 only: skip the additional f16x3 measurement reported under \"split_precision\"")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from a HIP graph (wavenet_speech_amd.GraphedStep: forward + backward + gradient gather in one "
+                         "graph, the all-reduce eager, the optimizer in a second graph).  auto = on for cfg2, whose ~280 launches of "
+                         "5-50 us take the host longer to issue than the GPU to run; off for the long-kernel configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seq-len", type=int, default=None)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -96,6 +100,7 @@ def parse():
             setattr(args, k, cfg[k])
     if args.cpu_seq_len is None:
         args.cpu_seq_len = args.seq_len
+    args.use_graph = args.graph == "on" or (args.graph == "auto" and args.config == "cfg2")
     if args.init is None:
         args.init = "conditioned" if (args.config == "cfg5" and args.precision in ("f16", "f16x3")) else "reference"
     return args
@@ -357,7 +362,8 @@ def main():
     W.set_precision(net, args.precision)
     nparams = sum(p.numel() for p in net.parameters())
     try:
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)   # same update rule, one multi-tensor kernel
+        # same update rule, one multi-tensor kernel; capturable = the step count lives on the device (needed inside a HIP graph)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True, capturable=bool(args.use_graph))
     except (TypeError, RuntimeError):
         opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     sync = FlatGradAllReduce(net.parameters())
@@ -380,6 +386,20 @@ def main():
             sync.reduce()
         opt.step()
 
+    gstep = None
+
+    def graphed_step(timed=False):
+        gstep.replay_forward_backward()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gstep.reduce()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            gstep.reduce()
+        gstep.step_optimizer()
+
     def fence():
         torch.cuda.synchronize()
         if distributed:
@@ -393,17 +413,42 @@ def main():
         log("warm-up step %d done" % i)
     fence()
     timing = not args.no_kernel_timing
-    if timing:
+    if args.use_graph:
+        # the timed steps are graph replays: the same launches as the eager step, issued by one host call.  Per-kernel HIP
+        # events cannot be recorded inside a replay, so the kernel table comes from eager steps AFTER the timed region.
+        gstep = W.GraphedStep(lambda: (forward() * cot).sum(), net.parameters(), optimizer=opt, sync=sync, warmup=1)
+        for i in range(max(1, args.warmup)):
+            graphed_step()
+        fence()
+        log("HIP graph captured; %d replayed warm-up step(s) done" % max(1, args.warmup))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graphed_step(timed=True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        gstep.check()
+    else:
+        if timing:
+            HF.profile_reset()
+            HF.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=True)
+        fence()
+        elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
+    log("timed %d steps: %.2f ms/step" % (args.steps, elapsed / args.steps * 1e3))
+    kern = {}
+    eager_ms = None
+    if timing and args.use_graph:
         HF.profile_reset()
         HF.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    own_elapsed = elapsed
-    log("timed %d steps: %.1f ms/step" % (args.steps, elapsed / args.steps * 1e3))
-    kern = {}
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        eager_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        log("eager steps for the kernel table: %.2f ms/step" % eager_ms)
     if timing:
         HF.profile_enable(False)
         kern = HF.profile_read()
@@ -585,6 +630,11 @@ def main():
                   "ms_per_step_by_rank": per_rank_ms, "grad_allreduce_ms_by_rank": per_rank_ar,
                   "grad_allreduce_payload_mb": round(sync.payload_bytes() / 1e6, 1)},
         "breakdown": breakdown, "roofline": roofline, "roofline_step": roofline_step, "kernels": kernels,
+        "launch": ({"mode": "hipgraph", "note": "timed steps are replays of a captured HIP graph (forward + backward + gradient gather; "
+                    "all-reduce eager; optimizer in a second graph): the same kernels as the eager step, one host call.  The kernel "
+                    "table and the roofline object were timed with HIP events over the same number of EAGER steps after the timed region",
+                    "eager_ms_per_step": round(eager_ms, 2) if eager_ms is not None else None}
+                   if args.use_graph else {"mode": "eager"}),
     }
     if second is not None:
         result["split_precision"] = second

@@ -292,6 +292,27 @@ int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const voi
                                const void* dg, const void* dr, const void* dskip, const wn_block_params* grads,
                                const float* dyn_inv_scale, void* workspace, size_t workspace_bytes, wn_stream_t stream);
 
+/* Every weight-pack job of a stack of blocks in ONE launch.  Training repacks all weights after each optimizer step (five
+ * launches per block through wn_hblock_pack, one per group through wn_hskipsum_pack); the jobs' arguments depend only on
+ * shapes, precision and pointers, so they are built ONCE into a table: wn_hstack_pack_table_build fills `table_host` (host
+ * memory of wn_hstack_pack_table_bytes(nblocks) bytes), the caller copies it to the device and keeps it; each step
+ * wn_hstack_pack_run(table_dev, ...) packs into `packed`, a device buffer of *packed_total bytes that may be a different
+ * allocation every time.  Block l's packed weights (what wn_hblock_forward / backward_* take) then start at
+ * packed + block_offsets[l]; with_skipsum != 0 also packs the long-K skips_sum weights of wn_hskipsum_forward from the
+ * blocks' w_skip / b_skip, group g (WN_MAX_STACK_GROUP blocks each) at packed + skipsum_offsets[g] -- the b_skip vectors
+ * must then be equally spaced in memory (WN_ERR_UNSUPPORTED otherwise: use the per-block entry points).
+ * `dynamic` (<= 3 ranges): parameter tensors inside one of these address ranges are re-allocated between steps; the table
+ * stores them as offsets and wn_hstack_pack_run receives the current bases, in the same order.  Rebuild the table when
+ * any other pointer, a shape or the precision changes.  (No reference counterpart: the reference has no packed weights.) */
+typedef struct wn_mem_range { const void* base; size_t bytes; } wn_mem_range;
+size_t wn_hstack_pack_table_bytes(int nblocks);
+int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_params* params, int nblocks, int precision,
+                               int with_skipsum, const wn_mem_range* dynamic, int ndynamic, void* table_host, size_t table_bytes,
+                               size_t* block_offsets, size_t* skipsum_offsets, size_t* packed_total, int* njobs,
+                               int* launch_blocks);
+int wn_hstack_pack_run(const void* table_dev, int nblocks, int njobs, int launch_blocks, const void* const* dynamic_bases,
+                       int ndynamic, void* packed, wn_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of every kernel on its launch stream ----
  * Kernel classes: index into wn_prof_kernel_name().  wn_prof_collect() synchronises the recorded
  * events and adds them to the per-class totals; wn_prof_get() reads them. */

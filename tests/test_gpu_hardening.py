@@ -45,6 +45,8 @@ def test_no_grad_takes_the_inference_branch_and_reuses_packed_weights():
         y_train = net(x)
         n_train = len(made)
         del made[:]
+        import wavenet_speech_amd as W
+        W.freeze_for_inference(net)          # keeping packed weights across forwards is opt-in (p.data updates are invisible)
         with torch.no_grad():
             y_eval = net(x)
             n_eval = len(made)
@@ -65,6 +67,28 @@ def test_no_grad_takes_the_inference_branch_and_reuses_packed_weights():
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     layers = net.layers
     assert O.rel_err(y3.cpu(), O.wavenet(x.cpu(), sd, layers, False)) < 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x3"])
+def test_data_updates_are_seen_by_unfrozen_inference(precision):
+    """p.data.mul_() bumps no autograd version: by default every forward packs the current weights, so the
+    output must follow; only freeze_for_inference keeps packed weights."""
+    import wavenet_speech_amd as W
+    net = _net(nblk=4)
+    W.set_precision(net, precision)
+    x = torch.randn(2, 16, 300, device=DEV)
+    with torch.no_grad():
+        y0 = net(x)
+        y0b = net(x)
+        net.convolutions[1].conv_sigmoid.conv1d.weight.data.mul_(2.0)
+        net.bottlenecks[2].weight.data.mul_(0.5)
+        y1 = net(x)
+        net.convolutions[1].conv_sigmoid.conv1d.weight.data.mul_(0.5)
+        net.bottlenecks[2].weight.data.mul_(2.0)
+        y2 = net(x)
+    assert torch.equal(y0, y0b)
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y0, y2)
 
 
 def test_last_block_residual_path_gets_no_gradient():

@@ -11,6 +11,10 @@ So in TRAINING calls the counter is copied to pinned host memory asynchronously 
 through here -- or by check_device_flags(), which waits.  The exception arrives one call late; the step that tripped it has
 NaN / inf results of its own.  Calls outside autograd (inference) check at once: their results are consumed directly.
 WN_FLAG_CHECK=sync checks at once everywhere.
+
+Under HIP-graph capture (graphs.GraphedStep) nothing may read back or record host-visible events: a flag noted while the
+current stream is capturing is only REMEMBERED (the tensor lives in the graph's memory and is rewritten by every replay);
+check_device_flags() reads the remembered ones too.
 """
 import os
 
@@ -24,10 +28,14 @@ class _Watch(object):
         self.pinned = None
         self.next = 0
         self.pending = []          # (slot, event, message)
+        self.captured = []         # (flag tensor in graph memory, message): flags of captured steps, re-read on demand
 
     def note(self, flag, message, at_once):
         """flag: int32 device tensor [1]; message: str or callable(count) -> str"""
         if flag is None:
+            return
+        if flag.is_cuda and torch.cuda.is_current_stream_capturing():
+            self.captured.append((flag, message))
             return
         if at_once or os.environ.get("WN_FLAG_CHECK") == "sync":
             n = int(flag.item())
@@ -46,6 +54,8 @@ class _Watch(object):
         self.pending.append((slot, ev, message))
 
     def poll(self, wait=False):
+        if not wait and self.pending and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return                     # no event queries from inside a capture
         keep, hit = [], None
         for slot, ev, message in self.pending:
             if wait:
@@ -57,6 +67,12 @@ class _Watch(object):
             else:
                 keep.append((slot, ev, message))
         self.pending = keep
+        if wait and hit is None:
+            for flag, message in self.captured:
+                n = int(flag.item())
+                if n:
+                    hit = message(n) if callable(message) else message
+                    break
         if hit is not None:
             raise RuntimeError(hit + " [reported after the call that tripped it]")
 

@@ -39,6 +39,11 @@ class SkipSumShape(Structure):
                 ("halo", c_int), ("channels", c_int * MAX_STACK_GROUP)]
 
 
+class MemRange(Structure):
+    """wn_mem_range"""
+    _fields_ = [("base", c_void_p), ("bytes", c_size_t)]
+
+
 class ConvShape(Structure):
     """wn_conv_shape"""
     _fields_ = [("batch", c_int), ("length", c_int), ("in_channels", c_int), ("out_channels", c_int),
@@ -88,6 +93,11 @@ SIGNATURES = {
     "wn_hskipsum_forward": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
     "wn_hblock_backward_data": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_float_p, c_float_p, c_void_p, c_void_p]),
+    "wn_hstack_pack_table_bytes": (c_size_t, [c_int]),
+    "wn_hstack_pack_table_build": (c_int, [POINTER(BlockShape), POINTER(BlockParams), c_int, c_int, c_int, POINTER(MemRange), c_int,
+                                           c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),
+                                           POINTER(c_int), POINTER(c_int)]),
+    "wn_hstack_pack_run": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "wn_hblock_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, POINTER(BlockParams), c_float_p, c_void_p, c_size_t, c_void_p]),

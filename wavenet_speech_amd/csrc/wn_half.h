@@ -71,19 +71,31 @@ struct HGemmArgs {
 };
 
 // ---- weight packing ------------------------------------------------------------------------------------------
+// Source pointers of a job are absolute, or -- in a job TABLE kept on the device and reused step after step
+// (wn_hstack_pack_*) -- byte offsets from one of the run-time bases the launch supplies (HPackDyn): tensors that are
+// allocated anew every step (the folded skip weights) then cost no table rebuild.
+enum { HPACK_DYN_MASK = 3, HPACK_PERM = 4 };
 struct HPackSrc {
     const float* ptr;       // nullptr => zeros
     int rows, cols;
     int stride_r, stride_c;
     float scale;            // multiplied into the weight (weight scale / input-tensor scale), exact power of two
-    int _pad;
+    int flags;              // bits 0-1: dynamic base id (0: ptr is absolute; i: ptr is a byte offset from HPackDyn::base[i - 1]);
+                            // HPACK_PERM: the 16 channels of a k-step are packed in accumulator order (wn_fused.hip: the gated z
+                            // tile stays in the MFMA result registers and is fed back as the B operand)
 };
 struct HPackSet {
     HPackSrc seg[kMaxSeg];
-    const float* bias0;
+    const float* bias0;     // summed: bias0[r + i * bias0_stride] for i < bias0_rep, + bias1[r]
     const float* bias1;
     int bias_rows;
     float bias_scale;
+    int bias0_dyn, bias1_dyn;      // dynamic base ids as in HPackSrc::flags
+    int bias0_rep, bias0_stride;   // rep <= 1: a single vector
+};
+struct HPackDyn {
+    const char* base[3];
+    char* out;              // table jobs: HPackArgs::wpacked / ::bias are byte offsets from here
 };
 struct HPackArgs {
     HPackSet set[2];
@@ -99,6 +111,7 @@ struct HPackArgs {
     float* bias;
     long long total_units;          // 16-byte units per plane over all slabs
 };
+static_assert(sizeof(HPackArgs) <= 4096, "HPackArgs travels as a kernel argument");
 
 // ---- dense fp32 <-> half series --------------------------------------------------------------------------------
 struct HLoadArgs {
@@ -138,8 +151,35 @@ struct HWgradArgs {
     long long slab_floats; int rs_floats;
 };
 
+// ---- fused block forward (wn_fused.hip): <= 128 channels, one-plane modes ----------------------------------------------------
+constexpr int kFRows = 128;                         // rows of every phase (gate half: [a ; g] of 64 channels; res; skip)
+constexpr int kFStageBytes = kFRows * 32 * 2;       // one ring stage: 32 channels of K for the 128 rows (8 KiB)
+constexpr int kFMaxGateK = 16;                      // 16-channel k-steps of the gate product: taps * round_up(Ci, 32) / 16
+struct HFusedArgs {
+    const char* wstream;        // the weights of all phases as ONE sequence of stages in consumption order: gate half 0, [gate half 1], res, skip
+    const float* bias;          // [4][128] fp32: accumulator start values (bias / output scale) of gate half 0 / 1, res, skip
+    const char* x;              // input half series
+    long long x_ustride;
+    HDst z, sg, r;              // base == nullptr: not stored
+    float* skip;                // dense fp32 [B][skip_rows][L] (inference) or nullptr
+    unsigned* flag;
+    int xunit[kFMaxGateK];      // 16-byte unit offset of gate k-step kk = (tap j, channels 16 ks ..): (2 ks) * ld + tap offset
+    int nkg, nci16, nzt, co;    // gate k-steps; round_up(Ci, 32) / 16; z tiles of 32 channels; valid z channels
+    int do_res, do_skip, skip_rows, skip_accum;
+    int jump_at, jump;          // stream stages >= jump_at are `jump` stages further on (res phase not run)
+    float osc_gate, osc_res, osc_skip;
+    int B, L, ld, halo, units_per_row, nunit, nstage;
+};
+hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st);
+
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);
 hipError_t launch_hpack(const HPackArgs& a, hipStream_t st);
+// every job of a device-resident table in one launch: jobs[j] covers thread blocks block0[j] .. block0[j + 1] - 1
+hipError_t launch_hpack_table(const HPackArgs* jobs, const int* block0, int njobs, int nblocks, const HPackDyn& dyn, hipStream_t st);
+inline long long hpack_threads(const HPackArgs& a) {
+    const long long nb = (long long)a.nslab * a.rows;
+    return a.total_units > nb ? a.total_units : nb;
+}
 hipError_t launch_hload(const HLoadArgs& a, hipStream_t st);
 hipError_t launch_hwgrad(int prec, const HWgradArgs& a, hipStream_t st);
 

@@ -79,8 +79,18 @@ hipError_t launch_hload(const HLoadArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing:  PyTorch-layout fp32 parameters -> [slab][k-step][plane][k-group 2][row][8] (the LDS image of a stage)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one thread = one 16-byte unit of plane 0 (+ plane 1)
+template <bool TABLE>
+__device__ __forceinline__ const float* hpack_src(const float* p, int dyn_id, const HPackDyn& d) {
+    const int id = dyn_id & HPACK_DYN_MASK;
+    if (!TABLE || id == 0) return p;   // (jobs passed as kernel arguments carry absolute pointers only)
+    const char* b = id == 1 ? d.base[0] : (id == 2 ? d.base[1] : d.base[2]);   // (a dynamically indexed array would live in scratch)
+    return reinterpret_cast<const float*>(b + reinterpret_cast<uintptr_t>(p));
+}
+
+// one thread = one 16-byte unit of plane 0 (+ plane 1); `a` lives in the kernel arguments (hpack_kernel) or in a device table
+// (hpack_table_kernel, where wpacked / bias are offsets from d.out)
+template <bool TABLE>
+__device__ __forceinline__ void hpack_body(const HPackArgs& a, const HPackDyn& d, char* wpacked, float* bias, long long idx) {
     if (idx < a.total_units) {
         const int KG = a.kgroups;
         const long long plane_bytes = (long long)KG * a.rows * 16;     // one k-step of one plane
@@ -102,20 +112,24 @@ __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
         if (t.row0 >= 0 && s < a.slab_nseg[slab]) {
             const HPackSrc src = a.set[t.set].seg[s];
             const int r = t.row0 + (row & 31);
-            if (src.ptr && r < src.rows) {
+            if (src.ptr != nullptr || (src.flags & HPACK_DYN_MASK)) {
+                const float* sp = hpack_src<TABLE>(src.ptr, src.flags, d);
+                if (r < src.rows) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = 8 * KG * (int)ks + 8 * kg + j;
-                    if (c < src.cols) v[j] = src.ptr[(long long)r * src.stride_r + (long long)c * src.stride_c] * src.scale;
+                    for (int j = 0; j < 8; ++j) {
+                        // accumulator order (KG == 2): slot (kg, j) of a 16-channel k-step holds channel 8 (j >> 2) + 4 kg + (j & 3)
+                        const int c = (src.flags & HPACK_PERM) ? 16 * (int)ks + 8 * (j >> 2) + 4 * kg + (j & 3) : 8 * KG * (int)ks + 8 * kg + j;
+                        if (c < src.cols) v[j] = sp[(long long)r * src.stride_r + (long long)c * src.stride_c] * src.scale;
+                    }
                 }
             }
         }
-        char* d = a.wpacked + a.slab_woff[slab] + ks_abs * kstep_bytes + ((long long)kg * a.rows + row) * 16;
+        char* dp = wpacked + a.slab_woff[slab] + ks_abs * kstep_bytes + ((long long)kg * a.rows + row) * 16;
         if (a.bf16) {
             b8 hi;
 #pragma unroll
             for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
-            *reinterpret_cast<b8*>(d) = hi;
+            *reinterpret_cast<b8*>(dp) = hi;
         } else {
             h8 hi, lo;
 #pragma unroll
@@ -123,12 +137,12 @@ __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
             hi = pin(hi);
 #pragma unroll
             for (int j = 0; j < 8; ++j) lo[j] = (_Float16)(v[j] - (float)hi[j]);
-            *reinterpret_cast<h8*>(d) = hi;
-            if (a.planes == 2) *reinterpret_cast<h8*>(d + plane_bytes) = lo;
+            *reinterpret_cast<h8*>(dp) = hi;
+            if (a.planes == 2) *reinterpret_cast<h8*>(dp + plane_bytes) = lo;
         }
     }
     const long long nb = (long long)a.nslab * a.rows;
-    if (idx < nb && a.bias) {
+    if (idx < nb && bias) {
         const int slab = (int)(idx / a.rows), rr = (int)(idx % a.rows);
         const PackTile t = a.tile[slab * (a.rows / 32) + rr / 32];
         float v = 0.0f;
@@ -136,21 +150,48 @@ __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
             const HPackSet& ps = a.set[t.set];
             const int r = t.row0 + (rr & 31);
             if (r < ps.bias_rows) {
-                if (ps.bias0) v += ps.bias0[r];
-                if (ps.bias1) v += ps.bias1[r];
+                if (ps.bias0 != nullptr || ps.bias0_dyn) {
+                    const float* b0 = hpack_src<TABLE>(ps.bias0, ps.bias0_dyn, d);
+                    const int rep = ps.bias0_rep > 1 ? ps.bias0_rep : 1;
+                    for (int i = 0; i < rep; ++i) v += b0[r + (long long)i * ps.bias0_stride];   // fixed order: bitwise reproducible
+                }
+                if (ps.bias1 != nullptr || ps.bias1_dyn) v += hpack_src<TABLE>(ps.bias1, ps.bias1_dyn, d)[r];
             }
             v *= ps.bias_scale;
         }
-        a.bias[a.slab_boff[slab] + rr] = v;
+        bias[a.slab_boff[slab] + rr] = v;
     }
 }
 
+__global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
+    const HPackDyn d = {{nullptr, nullptr, nullptr}, nullptr};
+    hpack_body<false>(a, d, a.wpacked, a.bias, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void hpack_table_kernel(const HPackArgs* jobs, const int* block0, int njobs, const HPackDyn d) {
+    // the job of this thread block: block0 is ascending, njobs is a few hundred at most (binary search on wave-uniform values)
+    int lo = 0, hi = njobs - 1;
+    const int bid = (int)blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (block0[mid] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const HPackArgs& a = jobs[lo];
+    char* wp = d.out + reinterpret_cast<uintptr_t>(a.wpacked);
+    float* bp = a.bias ? reinterpret_cast<float*>(d.out + reinterpret_cast<uintptr_t>(a.bias) - 1) : nullptr;   // offset + 1 (0 = no bias)
+    hpack_body<true>(a, d, wp, bp, (long long)(bid - block0[lo]) * 256 + threadIdx.x);
+}
+
 hipError_t launch_hpack(const HPackArgs& a, hipStream_t st) {
-    long long n = a.total_units;
-    const long long nb = (long long)a.nslab * a.rows;
-    if (nb > n) n = nb;
+    const long long n = hpack_threads(a);
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(hpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_hpack_table(const HPackArgs* jobs, const int* block0, int njobs, int nblocks, const HPackDyn& dyn, hipStream_t st) {
+    if (njobs <= 0 || nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(hpack_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs, block0, njobs, dyn);
     return hipGetLastError();
 }
 

@@ -127,8 +127,25 @@ struct HPlan {
     size_t bytes() const { return align256((size_t)wbytes) + align256((size_t)bfloats * 4); }
 };
 
+// fused forward (wn_fused.hip): one launch for gate -> z -> res (+ skip), z stays in registers.  One-plane modes, all channel
+// counts <= 128 (one wave owns every output channel of its 32 time columns), the gate's K within the x-fragment register budget.
+struct HFusedPlan {
+    bool on = false;
+    int nzt = 0, nci16 = 0, nkg = 0, ngh = 0;     // z tiles of 32 channels; cp32(Ci)/16; gate k-steps; gate halves of 64 channels
+    int st_gate = 0, st_res = 0, st_skip = 0;     // ring stages (32 channels of K x 128 rows) per gate half / res / skip phase
+    size_t off_w = 0, off_bias = 0;
+    int stages() const { return ngh * st_gate + st_res + st_skip; }
+    size_t bytes() const { return on ? align256((size_t)stages() * kFStageBytes) + align256(4 * kFRows * sizeof(float)) : 0; }
+};
+
+bool fused_forward_enabled() {
+    static const bool off = getenv("WN_FUSED_FWD") && atoi(getenv("WN_FUSED_FWD")) == 0;
+    return !off;
+}
+
 struct HBlockPlan {
     HPlan fa, fr, fs, ka, kb;
+    HFusedPlan fu;
     size_t off_fa = 0, off_fr = 0, off_fs = 0, off_ka = 0, off_kb = 0, total = 0;
 };
 
@@ -174,12 +191,21 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
     }
+    {
+        HFusedPlan& f = p.fu;
+        f.nci16 = cp32(Ci) / 16; f.nzt = cp32(Co) / 32; f.nkg = k * f.nci16; f.ngh = (f.nzt + 1) / 2;
+        f.st_gate = f.nkg / 2; f.st_res = f.nzt + f.nci16 / 2; f.st_skip = f.nzt;
+        f.on = fused_forward_enabled() && P == 1 && cp32(Ci) <= 128 && cp32(Co) <= 128 && Ms <= 128 && f.nkg <= kFMaxGateK;
+    }
+    // a block that runs the fused forward packs no separate gate / res / skip weights
     p.off_fa = 0;
-    p.off_fr = p.off_fa + p.fa.bytes();
-    p.off_fs = p.off_fr + p.fr.bytes();
-    p.off_ka = p.off_fs + p.fs.bytes();
+    p.off_fr = p.off_fa + (p.fu.on ? 0 : p.fa.bytes());
+    p.off_fs = p.off_fr + (p.fu.on ? 0 : p.fr.bytes());
+    p.off_ka = p.off_fs + (p.fu.on ? 0 : p.fs.bytes());
     p.off_kb = p.off_ka + p.ka.bytes();
-    p.total = p.off_kb + p.kb.bytes();
+    p.fu.off_w = p.off_kb + p.kb.bytes();
+    p.fu.off_bias = p.fu.off_w + align256((size_t)p.fu.stages() * kFStageBytes);
+    p.total = p.fu.off_w + p.fu.bytes();
     return p;
 }
 
@@ -203,7 +229,7 @@ void fill_hpack(HPackArgs& a, const HPlan& g, void* packed, size_t off, int prec
 }
 
 inline HPackSrc hsrc(const float* p, int rows, int cols, int sr, int sc, float scale) {
-    HPackSrc s; s.ptr = p; s.rows = rows; s.cols = cols; s.stride_r = sr; s.stride_c = sc; s.scale = scale; s._pad = 0; return s;
+    HPackSrc s; s.ptr = p; s.rows = rows; s.cols = cols; s.stride_r = sr; s.stride_c = sc; s.scale = scale; s.flags = 0; return s;
 }
 
 // tiles of a plain plan: row tile i of slab sl covers rows slab_row0 + 32 i
@@ -238,7 +264,7 @@ inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
 
 // profiling classes shared with wn_api.hip (same table, same order)
 enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
-       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD };
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED };
 
 }  // namespace
 
@@ -291,52 +317,106 @@ size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision) {
     return plan_hblock(s, precision).total;
 }
 
-int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream) {
+namespace {
+// the pack jobs of one block (gate, res, skip, dz, dx), `packed` = where the block's packed weights will live
+int fill_hblock_jobs(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, std::vector<HPackArgs>& jobs) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
     if (!p || !packed || !p->w_tanh || !p->w_sigmoid || !p->w_res || !p->w_skip || !p->w_proj) return WN_ERR_NULL;
-    hipStream_t st = (hipStream_t)stream;
     const HBlockPlan bp = plan_hblock(s, precision);
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     const float WS = kWeightScale, RS = kResidualScale;
-    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
     HPackArgs a;
-    {   // FA: gate rows; the input x is stored as x * RS
-        const HPlan& g = bp.fa;
-        fill_hpack(a, g, packed, bp.off_fa, precision);
-        for (int j = 0; j < k; ++j) {
-            a.set[0].seg[j] = hsrc(p->w_tanh + j, Co, Ci, Ci * k, k, WS / RS);
-            a.set[1].seg[j] = hsrc(p->w_sigmoid + j, Co, Ci, Ci * k, k, WS / RS);
-        }
-        a.set[0].bias0 = p->b_tanh; a.set[0].bias_rows = Co;
-        a.set[1].bias0 = p->b_sigmoid; a.set[1].bias_rows = Co;
-        const int tiles = g.rows / 32, per_wave = tiles / g.wave_rows();   // a wave owns per_wave consecutive tiles = per_wave/2 (a, g) pairs
-        for (int sl = 0; sl < g.nslab; ++sl)
-            for (int i = 0; i < tiles; ++i) {
-                const int wm = i / per_wave, tw = i % per_wave;            // wave row, tile inside the wave
-                const int ch0 = g.slab_row0[sl] + wm * 16 * per_wave + 32 * (tw / 2);
-                a.tile[sl * tiles + i].set = tw & 1;
-                a.tile[sl * tiles + i].row0 = ch0 < Co ? ch0 : -1;
+    if (bp.fu.on) {
+        // fused forward: every phase is 128 rows; the stream is gate half 0, [gate half 1], res, skip (wn_fused.hip).  The biases
+        // become accumulator start values: bias / (output scale of the phase) = bias * WS in all three cases.
+        const HFusedPlan& f = bp.fu;
+        auto blank = [&](int nslab, size_t woff, int boff_floats) {
+            std::memset(&a, 0, sizeof(a));
+            a.nslab = nslab; a.rows = kFRows; a.planes = 1; a.bf16 = precision == WN_BF16; a.kgroups = 2;
+            a.wpacked = (char*)packed + f.off_w + woff;
+            a.bias = reinterpret_cast<float*>((char*)packed + f.off_bias) + boff_floats;
+            a.set[0].bias_scale = a.set[1].bias_scale = WS;
+        };
+        {   // gate: slab = half of 64 channels, row tiles [a(c), g(c), a(c + 32), g(c + 32)]
+            blank(f.ngh, 0, 0);
+            for (int j = 0; j < k; ++j) {
+                a.seg_nks[j] = f.nci16;
+                a.set[0].seg[j] = hsrc(p->w_tanh + j, Co, Ci, Ci * k, k, WS / RS);
+                a.set[1].seg[j] = hsrc(p->w_sigmoid + j, Co, Ci, Ci * k, k, WS / RS);
             }
-        WN_HIP(launch_hpack(a, st), "hpack(gate)");
-    }
-    {   // FR: r = W_res z + W_proj x + b, stored as r * RS
-        const HPlan& g = bp.fr;
-        fill_hpack(a, g, packed, bp.off_fr, precision);
-        a.set[0].seg[0] = hsrc(p->w_res, Co, Co, Co, 1, WS);
-        a.set[0].seg[1] = hsrc(p->w_proj, Co, Ci, Ci, 1, WS / RS);
-        a.set[0].bias0 = p->b_res; a.set[0].bias1 = p->b_proj; a.set[0].bias_rows = Co; a.set[0].bias_scale = RS;
-        plain_tiles(a, g, Co);
-        WN_HIP(launch_hpack(a, st), "hpack(res)");
-    }
-    {   // FS: skip = W_skip z + b (fp32 out)
-        const HPlan& g = bp.fs;
-        fill_hpack(a, g, packed, bp.off_fs, precision);
-        a.set[0].seg[0] = hsrc(p->w_skip, Ms, Co, Co, 1, WS);
-        a.set[0].bias0 = p->b_skip; a.set[0].bias_rows = Ms;
-        plain_tiles(a, g, Ms);
-        WN_HIP(launch_hpack(a, st), "hpack(skip)");
+            a.set[0].bias0 = p->b_tanh; a.set[0].bias_rows = Co;
+            a.set[1].bias0 = p->b_sigmoid; a.set[1].bias_rows = Co;
+            for (int hf = 0; hf < f.ngh; ++hf) {
+                a.slab_woff[hf] = (long long)hf * f.st_gate * kFStageBytes; a.slab_nseg[hf] = k; a.slab_boff[hf] = kFRows * hf;
+                for (int i = 0; i < 4; ++i) {
+                    const int ch0 = 64 * hf + 32 * (i >> 1);
+                    a.tile[hf * 4 + i].set = i & 1;
+                    a.tile[hf * 4 + i].row0 = ch0 < Co ? ch0 : -1;
+                }
+            }
+            a.total_units = (long long)f.ngh * f.st_gate * kFStageBytes / 16;
+            jobs.push_back(a);
+        }
+        {   // res: K = [z in accumulator order ; x], stored as r * RS
+            blank(1, (size_t)f.ngh * f.st_gate * kFStageBytes, 2 * kFRows);
+            a.seg_nks[0] = 2 * f.nzt; a.seg_nks[1] = f.nci16;
+            a.set[0].seg[0] = hsrc(p->w_res, Co, Co, Co, 1, WS); a.set[0].seg[0].flags = HPACK_PERM;
+            a.set[0].seg[1] = hsrc(p->w_proj, Co, Ci, Ci, 1, WS / RS);
+            a.set[0].bias0 = p->b_res; a.set[0].bias1 = p->b_proj; a.set[0].bias_rows = Co;
+            a.slab_nseg[0] = 2;
+            for (int i = 0; i < 4; ++i) { a.tile[i].set = 0; a.tile[i].row0 = 32 * i < Co ? 32 * i : -1; }
+            a.total_units = (long long)f.st_res * kFStageBytes / 16;
+            jobs.push_back(a);
+        }
+        {   // skip (the per-block form of inference; training forms skips_sum afterwards from every block's z)
+            blank(1, (size_t)(f.ngh * f.st_gate + f.st_res) * kFStageBytes, 3 * kFRows);
+            a.seg_nks[0] = 2 * f.nzt;
+            a.set[0].seg[0] = hsrc(p->w_skip, Ms, Co, Co, 1, WS); a.set[0].seg[0].flags = HPACK_PERM;
+            a.set[0].bias0 = p->b_skip; a.set[0].bias_rows = Ms;
+            a.slab_nseg[0] = 1;
+            for (int i = 0; i < 4; ++i) { a.tile[i].set = 0; a.tile[i].row0 = 32 * i < Ms ? 32 * i : -1; }
+            a.total_units = (long long)f.st_skip * kFStageBytes / 16;
+            jobs.push_back(a);
+        }
+    } else {
+        {   // FA: gate rows; the input x is stored as x * RS
+            const HPlan& g = bp.fa;
+            fill_hpack(a, g, packed, bp.off_fa, precision);
+            for (int j = 0; j < k; ++j) {
+                a.set[0].seg[j] = hsrc(p->w_tanh + j, Co, Ci, Ci * k, k, WS / RS);
+                a.set[1].seg[j] = hsrc(p->w_sigmoid + j, Co, Ci, Ci * k, k, WS / RS);
+            }
+            a.set[0].bias0 = p->b_tanh; a.set[0].bias_rows = Co;
+            a.set[1].bias0 = p->b_sigmoid; a.set[1].bias_rows = Co;
+            const int tiles = g.rows / 32, per_wave = tiles / g.wave_rows();   // a wave owns per_wave consecutive tiles = per_wave/2 (a, g) pairs
+            for (int sl = 0; sl < g.nslab; ++sl)
+                for (int i = 0; i < tiles; ++i) {
+                    const int wm = i / per_wave, tw = i % per_wave;            // wave row, tile inside the wave
+                    const int ch0 = g.slab_row0[sl] + wm * 16 * per_wave + 32 * (tw / 2);
+                    a.tile[sl * tiles + i].set = tw & 1;
+                    a.tile[sl * tiles + i].row0 = ch0 < Co ? ch0 : -1;
+                }
+            jobs.push_back(a);
+        }
+        {   // FR: r = W_res z + W_proj x + b, stored as r * RS
+            const HPlan& g = bp.fr;
+            fill_hpack(a, g, packed, bp.off_fr, precision);
+            a.set[0].seg[0] = hsrc(p->w_res, Co, Co, Co, 1, WS);
+            a.set[0].seg[1] = hsrc(p->w_proj, Co, Ci, Ci, 1, WS / RS);
+            a.set[0].bias0 = p->b_res; a.set[0].bias1 = p->b_proj; a.set[0].bias_rows = Co; a.set[0].bias_scale = RS;
+            plain_tiles(a, g, Co);
+            jobs.push_back(a);
+        }
+        {   // FS: skip = W_skip z + b (fp32 out)
+            const HPlan& g = bp.fs;
+            fill_hpack(a, g, packed, bp.off_fs, precision);
+            a.set[0].seg[0] = hsrc(p->w_skip, Ms, Co, Co, 1, WS);
+            a.set[0].bias0 = p->b_skip; a.set[0].bias_rows = Ms;
+            plain_tiles(a, g, Ms);
+            jobs.push_back(a);
+        }
     }
     {   // KA: rows = z channel c; seg0 cols = skip row m: w_skip[m][c]; seg1 cols = r row m: w_res[m][c]
         const HPlan& g = bp.ka;
@@ -345,7 +425,7 @@ int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params
         a.set[0].seg[1] = hsrc(p->w_res, Co, Co, 1, Co, WS);
         plain_tiles(a, g, Co);
         a.bias = nullptr;
-        WN_HIP(launch_hpack(a, st), "hpack(dz)");
+        jobs.push_back(a);
     }
     {   // KB: rows = input channel; cols = output channel
         const HPlan& g = bp.kb;
@@ -357,8 +437,19 @@ int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params
         a.set[0].seg[2 * k] = hsrc(p->w_proj, Ci, Co, 1, Ci, WS);
         plain_tiles(a, g, Ci);
         a.bias = nullptr;
-        WN_HIP(launch_hpack(a, st), "hpack(dx)");
+        jobs.push_back(a);
     }
+    return WN_OK;
+}
+}  // namespace
+
+int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream) {
+    std::vector<HPackArgs> jobs;
+    int rc = fill_hblock_jobs(s, precision, p, packed, jobs);
+    if (rc != WN_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
+    for (const HPackArgs& a : jobs) WN_HIP(launch_hpack(a, st), "hpack(block)");
     return WN_OK;
 }
 
@@ -375,6 +466,32 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     const double BL = (double)s->batch * s->length;
     const HView vx = view(x, Ci, s->ld, P), vz = view(z, Co, s->ld, P);
+    if (bp.fu.on) {
+        const HFusedPlan& f = bp.fu;
+        HFusedArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.wstream = (const char*)packed + f.off_w;
+        fa.bias = reinterpret_cast<const float*>((const char*)packed + f.off_bias);
+        fa.x = vx.base; fa.x_ustride = vx.ustride;
+        fa.z = dst_of(vz);
+        if (sg) fa.sg = dst_of(view(sg, Co, s->ld, P));
+        if (r_out) fa.r = dst_of(view(r_out, Co, s->ld, P));
+        fa.skip = skip_dense; fa.skip_rows = Ms; fa.skip_accum = skip_accumulate ? 1 : 0;
+        fa.flag = overflow_flag;
+        for (int j = 0; j < k; ++j)
+            for (int ks = 0; ks < f.nci16; ++ks) fa.xunit[j * f.nci16 + ks] = 2 * ks * s->ld + off[j];
+        fa.nkg = f.nkg; fa.nci16 = f.nci16; fa.nzt = f.nzt; fa.co = Co;
+        fa.do_res = r_out ? 1 : 0; fa.do_skip = skip_dense ? 1 : 0;
+        fa.jump_at = r_out ? 0x7fffffff : f.ngh * f.st_gate; fa.jump = r_out ? 0 : f.st_res;
+        fa.osc_gate = 1.0f / kWeightScale; fa.osc_res = kResidualScale / kWeightScale; fa.osc_skip = 1.0f / kWeightScale;
+        fa.B = s->batch; fa.L = s->length; fa.ld = s->ld; fa.halo = s->halo;
+        fa.units_per_row = cdiv(s->length, 32); fa.nunit = s->batch * fa.units_per_row;
+        fa.nstage = f.ngh * f.st_gate + (r_out ? f.st_res : 0) + (skip_dense ? f.st_skip : 0);
+        wn::ProfScopeShared prof(KC_HFUSED, 2.0 * ((2.0 * Co) * (double)(k * Ci) + (r_out ? Co * (double)(Co + Ci) : 0.0) +
+                                                 (skip_dense ? Ms * (double)Co : 0.0)) * BL, st);
+        WN_HIP(launch_hfused_fwd(precision, fa, st), "hfused_fwd");
+        return WN_OK;
+    }
     HGemmArgs a;
     {
         const HPlan& g = bp.fa;
@@ -522,6 +639,134 @@ int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* pa
     a.out32 = skip_dense; a.out32_rows = s->skip_rows; a.out32_accum = accumulate ? 1 : 0;
     wn::ProfScopeShared prof(KC_HSKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
     WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_F32, a, st), "hgemm<skipsum>");
+    return WN_OK;
+}
+
+// ---- every pack job of a stack in one launch -------------------------------------------------------------------------------
+// Training repacks every weight after each optimizer step: five small launches per block plus the long-K skips_sum pack.
+// Their arguments depend only on shapes, precision and pointers, so they are built once into a TABLE that lives on the device
+// and one kernel runs all of them (hpack_table_kernel).  Destinations are offsets into ONE packed buffer of the whole stack
+// (a fresh allocation per forward costs no rebuild); sources inside a caller-declared "dynamic" range (tensors re-allocated
+// every step: the folded skip weights) are stored as offsets from that range's base, which the launch supplies.
+namespace {
+constexpr int kMaxDynamic = 3;
+int stack_jobs_upper_bound(int nblocks) { return 5 * nblocks + cdiv(nblocks, WN_MAX_STACK_GROUP); }   // (a fused-forward block also has 5: gate, res, skip, dz, dx)
+
+void encode_dynamic(const float*& ptr, int& flags, const wn_mem_range* dyn, int ndyn) {
+    if (!ptr) return;
+    for (int i = 0; i < ndyn; ++i) {
+        const char* b = (const char*)dyn[i].base;
+        const char* q = (const char*)ptr;
+        if (b && q >= b && q < b + dyn[i].bytes) {
+            ptr = reinterpret_cast<const float*>((uintptr_t)(q - b));
+            flags |= (i + 1);
+            return;
+        }
+    }
+}
+}  // namespace
+
+size_t wn_hstack_pack_table_bytes(int nblocks) {
+    if (nblocks <= 0) return 0;
+    const size_t nj = (size_t)stack_jobs_upper_bound(nblocks);
+    return align256(nj * sizeof(HPackArgs)) + align256((nj + 1) * sizeof(int));
+}
+
+int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_params* params, int nblocks, int precision,
+                               int with_skipsum, const wn_mem_range* dynamic, int ndynamic, void* table_host, size_t table_bytes,
+                               size_t* block_offsets, size_t* skipsum_offsets, size_t* packed_total, int* njobs_out,
+                               int* launch_blocks_out) {
+    if (!shapes || !params || !table_host || !block_offsets || !packed_total || !njobs_out || !launch_blocks_out) return WN_ERR_NULL;
+    if (nblocks <= 0 || ndynamic < 0 || ndynamic > kMaxDynamic || (ndynamic && !dynamic)) return WN_ERR_BAD_SHAPE;
+    if (!half_prec(precision)) return WN_ERR_UNSUPPORTED;
+    if (table_bytes < wn_hstack_pack_table_bytes(nblocks)) return WN_ERR_WORKSPACE;
+    std::vector<HPackArgs> jobs;
+    size_t total = 0;
+    for (int l = 0; l < nblocks; ++l) {
+        int off[WN_MAX_TAPS];
+        int rc = check_hblock(&shapes[l], precision, off);
+        if (rc != WN_OK) return rc;
+        block_offsets[l] = total;
+        rc = fill_hblock_jobs(&shapes[l], precision, &params[l], reinterpret_cast<void*>(total), jobs);
+        if (rc != WN_OK) return rc;
+        total += align256(plan_hblock(&shapes[l], precision).total);
+    }
+    if (with_skipsum) {
+        if (!skipsum_offsets) return WN_ERR_NULL;
+        // the biases of ALL blocks are summed into the first group's bias: they must be equally spaced (one stacked tensor)
+        long long bstride = 0;
+        for (int l = 1; l < nblocks; ++l) {
+            const long long d = params[l].b_skip - params[l - 1].b_skip;
+            if (l == 1) bstride = d;
+            else if (d != bstride) return WN_ERR_UNSUPPORTED;
+        }
+        if (bstride < 0 || bstride > 0x7fffffffLL) return WN_ERR_UNSUPPORTED;
+        for (int g0 = 0, gi = 0; g0 < nblocks; g0 += WN_MAX_STACK_GROUP, ++gi) {
+            wn_skipsum_shape ss;
+            std::memset(&ss, 0, sizeof(ss));
+            const int m = std::min(WN_MAX_STACK_GROUP, nblocks - g0);
+            ss.batch = shapes[0].batch; ss.length = shapes[0].length; ss.skip_rows = shapes[0].skip_rows; ss.nblocks = m;
+            ss.ld = shapes[0].ld; ss.halo = shapes[0].halo;
+            for (int i = 0; i < m; ++i) {
+                if (shapes[g0 + i].skip_rows != ss.skip_rows) return WN_ERR_BAD_SHAPE;
+                ss.channels[i] = shapes[g0 + i].out_channels;
+            }
+            int rc = check_hskipsum(&ss, precision);
+            if (rc != WN_OK) return rc;
+            const HPlan g = plan_hskipsum(&ss, precision);
+            HPackArgs a;
+            fill_hpack(a, g, reinterpret_cast<void*>(total), 0, precision);
+            for (int i = 0; i < m; ++i)
+                a.set[0].seg[i] = hsrc(params[g0 + i].w_skip, ss.skip_rows, ss.channels[i], ss.channels[i], 1, kWeightScale);
+            if (g0 == 0) {
+                a.set[0].bias0 = params[0].b_skip; a.set[0].bias0_rep = nblocks; a.set[0].bias0_stride = (int)bstride;
+            }
+            a.set[0].bias_rows = ss.skip_rows;
+            plain_tiles(a, g, ss.skip_rows);
+            jobs.push_back(a);
+            skipsum_offsets[gi] = total;
+            total += align256(g.bytes());
+        }
+    }
+    const int nj = (int)jobs.size();
+    if (nj > stack_jobs_upper_bound(nblocks)) return WN_ERR_WORKSPACE;
+    int* block0 = reinterpret_cast<int*>((char*)table_host + align256((size_t)stack_jobs_upper_bound(nblocks) * sizeof(HPackArgs)));
+    long long nb = 0;
+    for (int j = 0; j < nj; ++j) {
+        HPackArgs& a = jobs[j];
+        for (int st = 0; st < 2; ++st) {
+            for (int sg = 0; sg < kMaxSeg; ++sg) encode_dynamic(a.set[st].seg[sg].ptr, a.set[st].seg[sg].flags, dynamic, ndynamic);
+            encode_dynamic(a.set[st].bias0, a.set[st].bias0_dyn, dynamic, ndynamic);
+            encode_dynamic(a.set[st].bias1, a.set[st].bias1_dyn, dynamic, ndynamic);
+        }
+        if (a.bias) a.bias = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(a.bias) + 1);   // offset + 1: 0 stays "no bias"
+        block0[j] = (int)nb;
+        nb += (hpack_threads(a) + 255) / 256;
+        if (nb > 0x7fffffffLL) return WN_ERR_UNSUPPORTED;
+    }
+    block0[nj] = (int)nb;
+    std::memcpy(table_host, jobs.data(), (size_t)nj * sizeof(HPackArgs));
+    *packed_total = total;
+    *njobs_out = nj;
+    *launch_blocks_out = (int)nb;
+    return WN_OK;
+}
+
+int wn_hstack_pack_run(const void* table_dev, int nblocks, int njobs, int launch_blocks, const void* const* dynamic_bases, int ndynamic,
+                       void* packed, wn_stream_t stream) {
+    if (!table_dev || !packed) return WN_ERR_NULL;
+    if (nblocks <= 0 || njobs <= 0 || njobs > stack_jobs_upper_bound(nblocks) || launch_blocks <= 0 || ndynamic < 0 ||
+        ndynamic > kMaxDynamic || (ndynamic && !dynamic_bases))
+        return WN_ERR_BAD_SHAPE;
+    HPackDyn d;
+    std::memset(&d, 0, sizeof(d));
+    for (int i = 0; i < ndynamic; ++i) d.base[i] = (const char*)dynamic_bases[i];
+    d.out = (char*)packed;
+    const HPackArgs* jobs = reinterpret_cast<const HPackArgs*>(table_dev);
+    const int* block0 = reinterpret_cast<const int*>((const char*)table_dev + align256((size_t)stack_jobs_upper_bound(nblocks) * sizeof(HPackArgs)));
+    hipStream_t st = (hipStream_t)stream;
+    wn::ProfScopeShared prof(KC_PACK, 0.0, st);
+    WN_HIP(launch_hpack_table(jobs, block0, njobs, launch_blocks, d, st), "hpack(table)");
     return WN_OK;
 }
 

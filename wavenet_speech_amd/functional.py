@@ -68,6 +68,8 @@ def _p(x):
     """device pointer of a tensor / Lease / None"""
     if x is None:
         return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
     if isinstance(x, Lease):
         return ctypes.c_void_p(x.ptr)
     return ctypes.c_void_p(x.data_ptr())
@@ -189,7 +191,7 @@ class _ResidualStackFn(torch.autograd.Function):
                 raise RuntimeError("wavenet_speech_amd: all blocks of a stack must share out_dim")
             shape = _shape(spec, B, layout)
             params = _prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec)
-            if pack_cache is not None and not training:
+            if pack_cache is not None and pack_cache.frozen and not grad_enabled:
                 packed = pack_cache.get(l, layout, B)
                 if packed is None:
                     packed = pack_cache.put(l, layout, B, _pack_block(lib, shape, params, dev))
@@ -245,18 +247,25 @@ class _ResidualStackFn(torch.autograd.Function):
 
 
 class PackCache(object):
-    """Packed (MFMA-fragment order) weights of a stack, kept across forwards for inference: under torch.no_grad() the
-    weights do not change between calls, so re-packing them on every forward is wasted launches.  The owner (a module)
-    calls `validate(params)` before each use; any in-place update (optimizer step, load_state_dict) bumps a parameter's
-    `_version` and empties the cache."""
+    """Per-stack packing state.
+
+    * `tables` (always on): device-resident pack-job tables of the half-precision modes (functional_half.StackPackTable) --
+      they hold pointers and shapes, never weight VALUES, so every forward still packs the current weights (one launch).
+    * `packed` (only when `frozen`, see modules.block.freeze_for_inference): the packed weights themselves, kept across
+      no_grad forwards.  The owner calls `validate(params)` before each use; an in-place update through the autograd-visible
+      API (optimizer step, load_state_dict, p.mul_()) bumps a parameter's `_version` and empties the cache, so does a
+      parameter moving to other storage.  Updates through `p.data` (p.data.mul_(2)) are invisible to torch's version counter:
+      that is why keeping packed weights is opt-in."""
 
     def __init__(self):
         self.key = None
         self.packed = {}
         self.hits = 0
+        self.tables = {}           # device-resident pack-job tables (functional_half.StackPackTable), by their key
+        self.frozen = False        # keep packed weights / folded bottlenecks across no_grad forwards (opt-in)
 
     def validate(self, params, extra=()):
-        key = tuple((id(p), p._version, p.device) for p in params) + tuple(extra)
+        key = tuple((id(p), p._version, p.data_ptr(), p.device) for p in params) + tuple(extra)
         if key != self.key:
             self.key = key
             self.packed = {}

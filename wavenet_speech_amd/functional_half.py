@@ -70,10 +70,80 @@ def check_fp16_overflow():
     _flags.check_device_flags()
 
 
+def _grad_scale(cotangent, mode):
+    """(scale, 1 / scale) device scalars of a backward call: the dynamic power of two that puts max|cotangent| at GRAD_TARGET,
+    computed on the device (no host sync).  bf16 has fp32's exponent range: its gradients need no scaling (None, None)."""
+    if mode.dtype == torch.bfloat16:
+        return None, None
+    amax = cotangent.abs().amax().clamp_min(1e-30)
+    dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
+    return dyn, (1.0 / dyn).contiguous()
+
+
 def _load(lib, mode, dense, lease, layout, scale, dyn, flag):
     B, C, L = dense.shape
     _lib.check(lib.wn_hseries_load(mode.code, _p(dense), _p(lease), B, C, L, layout.ld, layout.halo, ctypes.c_float(scale),
                                    _p(dyn), _p(flag), _stream()), "wn_hseries_load")
+
+
+class StackPackTable(object):
+    """Device-resident table of every weight-pack job of a stack (wn_hstack_pack_*): built once per (shapes, precision, pointers),
+    then ONE launch per training step packs all blocks and the long-K skips_sum weights.  Parameters computed anew every step
+    (anything that is not an nn.Parameter: the folded bottleneck x skip products) are declared dynamic -- the table holds their offsets inside their
+    storages and each run supplies the storages' current addresses -- so steady-state training never rebuilds it."""
+    MAX_DYNAMIC = 3
+
+    @staticmethod
+    def dynamic_storages(flat):
+        """distinct storages of the tensors that are not nn.Parameters (recomputed every step), in first-seen order; None if too many"""
+        seen = []
+        for t in flat:
+            if not isinstance(t, torch.nn.Parameter):
+                st = t.untyped_storage()
+                if all(st.data_ptr() != q.data_ptr() for q in seen):
+                    seen.append(st)
+        return seen if len(seen) <= StackPackTable.MAX_DYNAMIC else None
+
+    @staticmethod
+    def key_of(specs, mode, B, layout, prepped, storages, skipsum):
+        dyn = [(st.data_ptr(), st.nbytes()) for st in storages]
+
+        def rel(t):
+            p = t.data_ptr()
+            for i, (b, n) in enumerate(dyn):
+                if b <= p < b + n:
+                    return ("d", i, p - b)
+            return p
+        return (mode.name, B, layout.key(), bool(skipsum), tuple(n for _, n in dyn),
+                tuple((s.ci, s.co, s.ms, s.k, s.d, s.causal) for s in specs), tuple(rel(t) for blk in prepped for t in blk))
+
+    def __init__(self, lib, specs, mode, B, layout, prepped, storages, skipsum, device):
+        n = len(specs)
+        shapes = (_lib.BlockShape * n)(*[_shape(s, B, layout) for s in specs])
+        params = (_lib.BlockParams * n)(*[_params_struct(blk) for blk in prepped])
+        dyn = (_lib.MemRange * max(1, len(storages)))(*[_lib.MemRange(st.data_ptr(), st.nbytes()) for st in storages])
+        nbytes = lib.wn_hstack_pack_table_bytes(n)
+        host = ctypes.create_string_buffer(nbytes)
+        offs = (ctypes.c_size_t * n)()
+        ngroups = (n + _lib.MAX_STACK_GROUP - 1) // _lib.MAX_STACK_GROUP
+        soffs = (ctypes.c_size_t * ngroups)()
+        total, njobs, nblocks = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(lib.wn_hstack_pack_table_build(shapes, params, n, mode.code, 1 if skipsum else 0, dyn, len(storages), host, nbytes,
+                                                  offs, soffs, ctypes.byref(total), ctypes.byref(njobs), ctypes.byref(nblocks)),
+                   "wn_hstack_pack_table_build")
+        self.table = torch.frombuffer(host, dtype=torch.uint8).to(device)       # the one host-to-device copy of the table's life
+        self.nblk, self.njobs, self.launch_blocks, self.ndyn = n, njobs.value, nblocks.value, len(storages)
+        self.block_offsets = list(offs)
+        self.skipsum_offsets = list(soffs)
+        self.total = total.value
+
+    def run(self, lib, storages, device):
+        """pack everything into a fresh buffer; returns it (block l at data_ptr() + block_offsets[l])"""
+        packed = torch.empty(self.total, dtype=torch.uint8, device=device)
+        bases = (ctypes.c_void_p * max(1, self.ndyn))(*[st.data_ptr() for st in storages])
+        _lib.check(lib.wn_hstack_pack_run(_p(self.table), self.nblk, self.njobs, self.launch_blocks, bases, self.ndyn, _p(packed),
+                                          _stream()), "wn_hstack_pack_run")
+        return packed
 
 
 class _HalfStackFn(torch.autograd.Function):
@@ -105,12 +175,38 @@ class _HalfStackFn(torch.autograd.Function):
         S = torch.empty(B, ms, L, dtype=torch.float32, device=dev)
         saved, skip_w, skip_b = [], [], []
         zbuf = None
-        for l, spec in enumerate(specs):
+        for spec in specs:
             if spec.ms != ms:
                 raise RuntimeError("wavenet_speech_amd: all blocks of a stack must share out_dim")
+        prepped = [_prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec) for l, spec in enumerate(specs)]
+        # every pack job of the stack (5 per block + in training the long-K skips_sum weights) from ONE launch of a device-resident
+        # job table (StackPackTable); WN_PACK_TABLE=0 or an unsupported layout falls back to the per-block entry points
+        table = packed_all = None
+        frozen = pack_cache is not None and pack_cache.frozen and not grad_enabled
+        if pack_cache is not None and not frozen and os.environ.get("WN_PACK_TABLE", "1") != "0":
+            storages = StackPackTable.dynamic_storages(flat)
+            if storages is not None:
+                key = StackPackTable.key_of(specs, mode, B, layout, prepped, storages, training)
+                table = pack_cache.tables.get(key)
+                if table is None:
+                    try:
+                        table = StackPackTable(lib, specs, mode, B, layout, prepped, storages, training, dev)
+                    except RuntimeError:
+                        table = False          # e.g. skip biases that are not equally spaced: per-block packing
+                    if len(pack_cache.tables) >= 8:
+                        pack_cache.tables.clear()
+                    pack_cache.tables[key] = table
+                if table:
+                    packed_all = table.run(lib, storages, dev)
+                else:
+                    table = None
+        for l, spec in enumerate(specs):
             shape = _shape(spec, B, layout)
-            params = _prep_params(flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK], spec)
-            packed = pack_cache.get(l, layout, B) if (pack_cache is not None and not training) else None
+            params = prepped[l]
+            if table is not None:
+                packed = packed_all.data_ptr() + table.block_offsets[l]
+            else:
+                packed = pack_cache.get(l, layout, B) if (pack_cache is not None and pack_cache.frozen and not grad_enabled) else None
             if packed is None:
                 nbytes = lib.wn_hblock_packed_bytes(ctypes.byref(shape), mode.code)
                 if nbytes == 0:
@@ -119,7 +215,7 @@ class _HalfStackFn(torch.autograd.Function):
                 ps = _params_struct(params)
                 _lib.check(lib.wn_hblock_pack(ctypes.byref(shape), mode.code, ctypes.byref(ps), _p(packed), _stream()),
                            "wn_hblock_pack")
-                if pack_cache is not None and not training:
+                if pack_cache is not None and pack_cache.frozen and not grad_enabled:
                     pack_cache.put(l, layout, B, packed)
             r = _hlease(mode, B, spec.co, layout, dev) if l + 1 < n else None
             if training:
@@ -138,24 +234,28 @@ class _HalfStackFn(torch.autograd.Function):
                 skip_b.append(params[7])
             cur = r
         if training:
-            bias_total = torch.stack(skip_b).sum(0).contiguous()
             G = _lib.MAX_STACK_GROUP
-            for g0 in range(0, n, G):
+            bias_total = torch.stack(skip_b).sum(0).contiguous() if table is None else None
+            for gi, g0 in enumerate(range(0, n, G)):
                 idx = range(g0, min(g0 + G, n))
                 m = len(idx)
                 shape = _lib.SkipSumShape(B, L, ms, m, layout.ld, layout.halo)
                 for i, l in enumerate(idx):
                     shape.channels[i] = specs[l].co
-                nbytes = lib.wn_hskipsum_packed_bytes(ctypes.byref(shape), mode.code)
-                if nbytes == 0:
-                    _lib.check(-1, "wn_hskipsum_packed_bytes")
-                packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                wptrs = (ctypes.c_void_p * m)(*[skip_w[l].data_ptr() for l in idx])
                 zptrs = (ctypes.c_void_p * m)(*[saved[l][2].ptr for l in idx])
-                _lib.check(lib.wn_hskipsum_pack(ctypes.byref(shape), mode.code, wptrs, _p(bias_total) if g0 == 0 else None,
-                                                _p(packed), _stream()), "wn_hskipsum_pack")
+                if table is not None:
+                    packed = packed_all.data_ptr() + table.skipsum_offsets[gi]
+                else:
+                    nbytes = lib.wn_hskipsum_packed_bytes(ctypes.byref(shape), mode.code)
+                    if nbytes == 0:
+                        _lib.check(-1, "wn_hskipsum_packed_bytes")
+                    packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    wptrs = (ctypes.c_void_p * m)(*[skip_w[l].data_ptr() for l in idx])
+                    _lib.check(lib.wn_hskipsum_pack(ctypes.byref(shape), mode.code, wptrs, _p(bias_total) if g0 == 0 else None,
+                                                    _p(packed), _stream()), "wn_hskipsum_pack")
                 _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
                                                    0 if g0 == 0 else 1, _stream()), "wn_hskipsum_forward")
+        ctx.packed_all = packed_all       # the blocks' packed weights live here until backward has run
         _flags.WATCH.note(flag, _OVERFLOW_MSG % "forward pass", at_once=not training)
         ctx.specs, ctx.saved, ctx.layout, ctx.batch, ctx.mode = specs, saved, layout, B, mode
         ctx.param_shapes = [tuple(t.shape) for t in flat]
@@ -171,10 +271,7 @@ class _HalfStackFn(torch.autograd.Function):
         dev = d_skips.device
         d_skips = d_skips.contiguous()
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
-        # dynamic power-of-two scale of the whole gradient domain, computed on the device (no host sync)
-        amax = d_skips.abs().amax().clamp_min(1e-30)
-        dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
-        dyn_inv = (1.0 / dyn).contiguous()
+        dyn, dyn_inv = _grad_scale(d_skips, mode)
         dS = _hlease(mode, B, specs[0].ms, layout, dev)
         _load(lib, mode, d_skips, dS, layout, 1.0, dyn, flag)
         dr = None
@@ -270,9 +367,7 @@ class _HalfConvFn(torch.autograd.Function):
         dev = d_y.device
         d_y = d_y.contiguous()
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
-        amax = d_y.abs().amax().clamp_min(1e-30)
-        dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
-        dyn_inv = (1.0 / dyn).contiguous()
+        dyn, dyn_inv = _grad_scale(d_y, mode)
         dy = _hlease(mode, B, Co, layout, dev)
         _load(lib, mode, d_y, dy, layout, 1.0, dyn, flag)
         dx = None

@@ -147,18 +147,37 @@ def set_precision(module, precision):
     return module
 
 
+def freeze_for_inference(module, on=True):
+    """Keep the packed weights and the folded bottlenecks of the residual stacks of `module` across no_grad forwards (by
+    default every forward packs the current weights again: one launch per stack in the half-precision modes, four small
+    launches per block in the fp32 mode).  The cache is emptied when a parameter's autograd version changes (optimizer step,
+    load_state_dict, p.mul_()) or a parameter moves; updates written through `p.data` are NOT seen -- call
+    freeze_for_inference(module) again after such an update to drop the cache."""
+    n = 0
+    for m in module.modules():
+        st = getattr(m, "stack_state", None)
+        if isinstance(st, StackState):
+            tables = st.cache.tables
+            st.cache = HF.PackCache()
+            st.cache.tables = tables
+            st.cache.frozen = bool(on)
+            st.folded = None
+            n += 1
+    if n == 0:
+        raise ValueError("freeze_for_inference: no residual stack in %s" % type(module).__name__)
+    return module
+
+
 def run_stack(out, blocks, bottlenecks, state=None):
     """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path"""
     specs, flat = [], []
     out_dim = bottlenecks[0].out_channels
     blocks, bottlenecks = list(blocks), list(bottlenecks)
     precision = state.precision if state is not None else "f32"
-    cache = None
-    inference = state is not None and not torch.is_grad_enabled()
-    if inference:
-        # nothing is differentiated: the folds and the packed weights depend only on the parameters, keep them
-        # until one of those is updated in place (its _version changes) or replaced
-        cache = state.cache
+    cache = state.cache if state is not None else None   # pack-job tables; for a frozen model also the packed weights
+    if state is not None and cache.frozen and not torch.is_grad_enabled():
+        # freeze_for_inference: the folds and the packed weights depend only on the parameters, keep them until one of
+        # those is updated in place (its _version changes) or moves to other storage
         params = [p for m in blocks + bottlenecks for p in m.parameters()]
         old_key = cache.key
         cache.validate(params, (precision,))

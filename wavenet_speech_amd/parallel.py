@@ -91,6 +91,11 @@ class FlatGradAllReduce(object):
         """gather + all-reduce (+ 1/world).  async_op=True returns a handle whose wait() completes the collective AND
         applies the 1/world average (call it before optimizer.step()); otherwise returns None when done."""
         self.gather()
+        return self.reduce_gathered(async_op)
+
+    def reduce_gathered(self, async_op=False):
+        """the collective half of reduce(): all-reduce (+ 1/world) of a flat buffer that gather() has already filled (the
+        gather of a HIP-graph-captured step is part of the graph, the all-reduce runs between the graphs: graphs.GraphedStep)"""
         if not (dist.is_available() and dist.is_initialized()):
             return _Done() if async_op else None
         w = self.world()

@@ -41,6 +41,7 @@ class _Pool(object):
 
     def __init__(self):
         self._free = collections.OrderedDict()   # key -> list of tensors, most recently used key last
+        self.hold = None                         # while a HIP graph is being captured: every buffer handed out is also kept here
         self._lock = threading.Lock()
         self.free_bytes = 0
         env = os.environ.get("WN_POOL_CAP_GB")
@@ -112,6 +113,8 @@ class Lease(object):
                 POOL.clear()
                 torch.cuda.empty_cache()
                 t = torch.zeros(batch, cp, ld, dtype=dtype, device=dev)
+        if POOL.hold is not None:
+            POOL.hold.append(t)      # a captured graph addresses this buffer for as long as it is replayed (graphs.GraphedStep)
         self.t = t
         self.ptr = t.data_ptr()
         self.channels = channels
