@@ -270,7 +270,11 @@ size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision);
 int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream);
 /* x, r_out (nullable), sg (nullable: inference), z: half series.  z = tanh(a) sigmoid(g) and sg = sigmoid(g) are what the
  * backward pass needs (the tanh is recovered as z / sg: one tensor less to write and to keep).  skip_dense (nullable): dense
- * fp32 [B][Ms][L] that receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference. */
+ * fp32 [B][Ms][L] that receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference.
+ * Blocks of <= 128 channels with two taps run as ONE launch in the one-plane modes (wn_hblock_forward_is_fused() == 1: gate,
+ * z and both products fused, z never leaves the chip between them -- the span modules/block.py:65-79 of the reference); there z
+ * may be NULL when sg is NULL (inference: nothing needs it).  The fused kernel writes to a 1 KiB scratch line inside `packed`. */
+int wn_hblock_forward_is_fused(const wn_block_shape* s, int precision);
 int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
                       float* skip_dense, int skip_accumulate, void* sg, void* z, unsigned* overflow_flag,
                       wn_stream_t stream);

@@ -27,14 +27,15 @@ def _asm(src, tmp_path):
 
 
 def test_ring_kernels_keep_their_prefetch_in_flight(tmp_path):
-    files = [_asm("wn_half.hip", tmp_path), _asm("wn_half_wgrad.hip", tmp_path)]
+    files = [_asm("wn_half.hip", tmp_path), _asm("wn_half_wgrad.hip", tmp_path), _asm("wn_fused.hip", tmp_path)]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rings.py")] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 42, r.stdout     # 15 hgemm (12 at 128 rows, 3 at 256) + 24 hgemm8 + 3 hwgrad instantiations
+    # 15 hgemm (12 at 128 rows, 3 at 256) + 24 hgemm8 + 3 hwgrad + 24 fused-forward instantiations
+    assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 66, r.stdout
 
 
-@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_embed.hip", "wn_nll.hip",
-                                 "wn_pack.hip"])
+@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_embed.hip",
+                                 "wn_nll.hip", "wn_pack.hip"])
 def test_no_kernel_uses_scratch(src, tmp_path):
     text = open(_asm(src, tmp_path)).read()
     sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)

@@ -11,7 +11,7 @@ import re, subprocess, sys
 bad = 0
 for path in sys.argv[1:]:
     s = open(path).read()
-    for m in re.finditer(r"^(_ZN2wn\w*(?:hgemm_kernel|hgemm8_kernel|hwgrad_kernel)\w*):[^\n]*\n(.*?)\n\.Lfunc_end", s, re.S | re.M):
+    for m in re.finditer(r"^(_ZN2wn\w*(?:hgemm_kernel|hgemm8_kernel|hwgrad_kernel|hfused_fwd_kernel)\w*):[^\n]*\n(.*?)\n\.Lfunc_end", s, re.S | re.M):
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
         lines = [l.strip() for l in m.group(2).splitlines()]
         bars = [i for i, l in enumerate(lines) if l == "s_barrier"]

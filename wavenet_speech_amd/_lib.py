@@ -86,6 +86,7 @@ SIGNATURES = {
                                 c_void_p]),
     "wn_hblock_packed_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_pack": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p]),
+    "wn_hblock_forward_is_fused": (c_int, [POINTER(BlockShape), c_int]),
     "wn_hblock_forward": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     "wn_hskipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape), c_int]),

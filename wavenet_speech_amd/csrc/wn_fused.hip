@@ -57,9 +57,20 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 }
 }  // namespace
 
-template <bool BF>
+// NZT = z tiles of 32 channels = round_up(C, 32) / 32 (Ci and Co round to the same value, two taps): every loop bound below
+// is a compile-time constant and the stream of stages is straight-line code.  That is not cosmetic: with a branch anywhere
+// between a global load and its use hipcc's wait insertion falls back to `s_waitcnt vmcnt(0)` -- a drain of the whole LDS-DMA
+// ring in front of every stage (the first version: 1100 cycles per stage instead of ~300) -- and with a branch between the
+// MFMAs of a stage it serialises fragment read -> wait -> MFMA.
+// MODE 0 (training): z and sigmoid(g) are stored (both required), no skip phase (training forms skips_sum afterwards from every
+// block's z).  MODE 1 (inference): sigmoid(g) is not stored, z only if the caller wants it, skips_sum accumulated here when
+// asked for.  MODE 2: a stand-alone block that wants everything (z, sigmoid(g), r and its skip output).
+template <bool BF, int NZT, int MODE>
 __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) {
+    constexpr bool TRAIN = MODE != 1, SKIP = MODE != 0;
     typedef typename FT<BF>::v8 V8;
+    constexpr int NCI16 = 2 * NZT, NKG = 4 * NZT;             // k-steps of 16 channels per tap / of the gate product
+    constexpr int NGH = (NZT + 1) / 2;                        // gate halves of 64 channels
     __shared__ __attribute__((aligned(1024))) char lds[kFD * kFStageBytes];
     __shared__ __attribute__((aligned(16))) float lbias[4 * kFRows];
 
@@ -73,28 +84,19 @@ __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) 
     const int per = (nwg + 7) >> 3;
     const int wg = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
     if (wg >= nwg) return;                                    // the whole workgroup leaves together
-    const int unit = wg * 4 + wave;
-    const bool active = unit < a.nunit;                       // wave-uniform; an idle wave still stages, waits and syncs
-    const int b = active ? unit / a.units_per_row : 0;
-    const int t0 = active ? (unit - b * a.units_per_row) * 32 : 0;
+    // a wave past the last unit recomputes the last one and stores nothing (no branch around the wave's work)
+    const int unit_raw = wg * 4 + wave;
+    const int unit = unit_raw < a.nunit ? unit_raw : a.nunit - 1;
+    const int b = unit / a.units_per_row;
+    const int t0 = (unit - b * a.units_per_row) * 32;
     const int t = t0 + r;
-    const bool col_ok = active && t < a.L;
+    const bool col_ok = unit_raw < a.nunit && t < a.L && !(a.dbg & 1);
     const int ld = a.ld;
 
     // ---- accumulator start values (bias / output scale) of the four phases -> LDS ----------------------------------------
-    for (int i = tid; i < 4 * kFRows; i += 256) lbias[i] = a.bias[i];
-
-    // ---- the unit's x fragments for the gate product: k-step kk = (tap, 16 channels), straight from the half series -------
-    const char* xb = a.x + (long long)b * a.x_ustride + ((long long)a.halo + t) * 16;
-    const long long hld = (long long)h * ld * 16;
-    V8 xf[kFMaxGateK];
-#pragma unroll
-    for (int kk = 0; kk < kFMaxGateK; ++kk) {
-        if (kk < a.nkg && active) xf[kk] = *reinterpret_cast<const V8*>(xb + (long long)a.xunit[kk] * 16 + hld);
-        else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xf[kk][j] = 0;
-        }
+    {
+        const f32x4 bv = reinterpret_cast<const f32x4*>(a.bias)[tid & 127];
+        if (tid < 128) reinterpret_cast<f32x4*>(lbias)[tid] = bv;
     }
 
     // ---- weight ring ------------------------------------------------------------------------------------------------------
@@ -106,15 +108,32 @@ __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) 
         char* dst = lds + slot * kFStageBytes + wave * 1024;
 #pragma unroll
         for (int p = 0; p < kFPW; ++p) WN_GLDS(src + p * 4096, lane16, dst + p * 4096);
-        if (is_stage + 1 < a.nstage) ++is_stage;             // past the end the last stage is staged again (never read)
+        is_stage = is_stage + 1 < a.nstage ? is_stage + 1 : is_stage;   // past the end the last stage is staged again (never read)
     };
 #pragma unroll
     for (int s = 0; s < kFD - 1; ++s) issue(s);
+
+    // ---- the unit's x fragments, straight from the half series: gate k-step kk = (tap, 16 channels), and x(t) for the
+    // projection (often no tap has offset 0).  hipcc inserts its own waits for these registers and counts only the loads IT
+    // knows: with the (inline-asm) DMA pieces of the ring in flight behind them, its `vmcnt(15) .. vmcnt(0)` ladder over the
+    // first eight stages drained the ring step by step.  So the loads are issued AFTER the ring's prologue and waited for
+    // right here with a wait the compiler can see: from then on it knows of no pending load and inserts none.  (The wait
+    // also covers the prologue's seven stages, which were issued first and are needed next anyway.)
+    const char* xb = a.x + (long long)b * a.x_ustride + ((long long)a.halo + t) * 16 + (long long)h * ld * 16;
+    V8 xf[NKG], xp[NCI16];
+#pragma unroll
+    for (int kk = 0; kk < NKG; ++kk) xf[kk] = *reinterpret_cast<const V8*>(xb + (long long)a.xunit[kk] * 16);
+#pragma unroll
+    for (int ks = 0; ks < NCI16; ++ks) xp[ks] = *reinterpret_cast<const V8*>(xb + (long long)(2 * ks) * ld * 16);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0) expcnt(7) lgkmcnt(15)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's lbias writes
     __builtin_amdgcn_s_barrier();
 
+    unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // measurement (WN_FUSED_STAMPS): s_memtime at the phase boundaries of wave 0
+    auto stamp = [&](int i) { if (a.stamps) tstamp[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     int gs = 0;                                               // stages consumed so far
-    const unsigned a_rd = (unsigned)((h * kFRows + r) * 16);  // this lane's fragment of row tile 0, k-step 0 of a stage
+    const char* a_rd = lds + (h * kFRows + r) * 16;           // this lane's fragment of row tile 0, k-step 0 of slot 0
     f32x16 acc[4];
     auto init_acc = [&](int phase) {
 #pragma unroll
@@ -126,30 +145,36 @@ __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) 
                 for (int q = 0; q < 4; ++q) acc[m][4 * i + q] = v[q];
             }
     };
-    // one stage = two k-steps of 16 channels for the 128 rows of the phase: wait for it, free the previous slot, prefetch
-    // the stage kFD - 1 ahead into it, then 8 fragment reads + 8 MFMAs
-    auto stage = [&](const V8& b0, const V8& b1) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFInflight) : "memory");
+    // One stage = two k-steps of 16 channels for the 128 rows of the phase: wait for it, free the previous slot, prefetch the
+    // stage kFD - 1 ahead into it, then 8 fragment reads in flight and 8 MFMAs.
+    // EXTRA = epilogue stores issued since this stage's pieces were: they sit in the same in-order vmcnt queue, so counted
+    // exactly the wait never depends on a store being acknowledged by HBM.  Only stores that are CERTAINLY issued are counted
+    // (store_tile is unconditional: masked lanes write to a dump line); anything uncounted makes a wait stricter, never weaker.
+    auto stage = [&](auto extra_c, const V8& b0, const V8& b1) {
+        constexpr int EXTRA = decltype(extra_c)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFInflight + EXTRA) : "memory");
         __builtin_amdgcn_s_barrier();
         const int slot = gs & (kFD - 1);
         issue((gs + kFD - 1) & (kFD - 1));
         ++gs;
-        if (active) {
-            const char* st = lds + slot * kFStageBytes + a_rd;
+        const char* st = a_rd + slot * kFStageBytes;
+        // all eight fragment reads in flight, then the MFMAs, each waiting for its own fragment only (lgkmcnt counts down)
+        V8 af[8];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                V8 af[4];
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const V8*>(st + (i >> 2) * 4096 + (i & 3) * 512);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = *reinterpret_cast<const V8*>(st + kk * 4096 + m * 512);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = mfma32<BF>(af[m], kk ? b1 : b0, acc[m]);
-            }
-        }
+        for (int i = 0; i < 8; ++i) acc[i & 3] = mfma32<BF>(af[i], (i >> 2) ? b1 : b0, acc[i & 3]);
+        __builtin_amdgcn_sched_barrier(0);
     };
+    // stage number `s` of a phase whose predecessor epilogue issued NST stores: they are younger than the pieces of the first
+    // kFD - 1 stages after it
+    #define WN_EXTRA(s, NST) std::integral_constant<int, ((s) < kFD - 1 ? (NST) : 0)>{}
 
     // a 32 x 32 tile of packed results (8 dwords = 16 channels-in-accumulator-order per lane) -> the half series, 16 bytes per lane:
     // registers 4i..4i+3 are channels 8i + 4h .. + 3 of the tile = half a unit; v_permlane32_swap of groups (2p, 2p + 1) gives lanes
-    // 0-31 the whole unit of group 2p and lanes 32-63 that of group 2p + 1
+    // 0-31 the whole unit of group 2p and lanes 32-63 that of group 2p + 1.  Two store instructions, always issued.
+    char* const dump = a.dump + lane * 16;                    // columns past the end of the utterance: same instruction, harmless address
     auto store_tile = [&](const HDst& d, int tile, const unsigned (&pk)[8]) {
         char* base = d.base + (long long)b * d.ustride + ((long long)(4 * tile + h) * ld + a.halo + t) * 16;
 #pragma unroll
@@ -158,106 +183,113 @@ __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) 
             const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-            if (col_ok) *reinterpret_cast<u32x4*>(base + (long long)(2 * p) * ld * 16) = v;
+            *reinterpret_cast<u32x4*>(col_ok ? base + (long long)(2 * p) * ld * 16 : dump) = v;
         }
     };
 
     // ---- gate phases: 64 z channels (two tiles) at a time ---------------------------------------------------------------------
-    V8 zf[4][2];                                              // z as the B operand of the next products: [tile][k-step]
-    const float og = a.osc_gate;
+    V8 zf[NZT][2];                                            // z as the B operand of the next products: [tile][k-step]
+    const float kt = a.osc_gate * (2.0f * kLog2e), ks = -a.osc_gate * kLog2e;   // accumulator -> exponent of the tanh / sigmoid
     const bool ragged_co = (a.co & 31) != 0;
+    const bool keep_z = TRAIN || a.z.base != nullptr;
+    constexpr int GST = NKG / 2;                              // stages per gate half
     [&]<int... HF>(std::integer_sequence<int, HF...>) {
         ([&] {
             constexpr int hf = HF;
-            if (2 * hf < a.nzt) {
-                init_acc(hf);
+            constexpr int TILES = NZT - 2 * hf >= 2 ? 2 : 1;  // z tiles of this half
+            constexpr int PREV = (hf == 0 || !TRAIN) ? 0 : 8; // counted stores of the previous half's epilogue (two tiles, z and sg)
+            init_acc(hf);
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (stage(WN_EXTRA(S, PREV), xf[2 * S], xf[2 * S + 1]), ...);
+            }(std::make_integer_sequence<int, GST>{});
+            if (hf == 0) stamp(1);
+            // (the pad-channel masking of channel counts that are not multiples of 32 lives in its own copy of the epilogue: a
+            // per-element branch or select in the common path costs more than the tanh)
+            auto epilogue = [&](auto ragged_c) {
+                constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
-                for (int s = 0; s < kFMaxGateK / 2; ++s)
-                    if (2 * s < a.nkg) stage(xf[2 * s], xf[2 * s + 1]);
-                if (active) {
+                for (int j = 0; j < TILES; ++j) {
+                    const int tile = 2 * hf + j;
+                    unsigned zpk[8], spk[8];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int tile = 2 * hf + j;
-                        unsigned zpk[8], spk[8];
+                    for (int d = 0; d < 8; ++d) {
+                        float zv[2], sv[2];
 #pragma unroll
-                        for (int d = 0; d < 8; ++d) {
-                            float zv[2], sv[2];
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int q = 2 * d + e;
-                                const float ta = h_tanh(acc[2 * j][q] * og);
-                                float s_ = h_sigmoid(acc[2 * j + 1][q] * og);
-                                float z_ = ta * s_;
-                                if (ragged_co) {              // pad channels stay exactly zero in the series
-                                    const int ch = 32 * tile + (q & 3) + 8 * (q >> 2) + 4 * h;
-                                    if (ch >= a.co) { s_ = 0.0f; z_ = 0.0f; }
-                                }
-                                zv[e] = z_; sv[e] = s_;
+                        for (int e = 0; e < 2; ++e) {
+                            const int q = 2 * d + e;
+                            const float ta = h_tanh_pre(acc[2 * j][q] * kt);
+                            float s_ = h_sigmoid_pre(acc[2 * j + 1][q] * ks);
+                            float z_ = ta * s_;
+                            if constexpr (RAGGED) {           // pad channels stay exactly zero in the series
+                                const int ch = 32 * tile + (q & 3) + 8 * (q >> 2) + 4 * h;
+                                s_ = ch < a.co ? s_ : 0.0f;
+                                z_ = ch < a.co ? z_ : 0.0f;
                             }
-                            zpk[d] = pack2<BF>(zv[0], zv[1]);
-                            spk[d] = pack2<BF>(sv[0], sv[1]);
+                            zv[e] = z_; sv[e] = s_;
                         }
-                        zf[2 * hf + j][0] = __builtin_bit_cast(V8, u32x4{zpk[0], zpk[1], zpk[2], zpk[3]});
-                        zf[2 * hf + j][1] = __builtin_bit_cast(V8, u32x4{zpk[4], zpk[5], zpk[6], zpk[7]});
-                        if (tile < a.nzt) {
-                            if (a.z.base) store_tile(a.z, tile, zpk);
-                            if (a.sg.base) store_tile(a.sg, tile, spk);
-                        }
+                        zpk[d] = pack2<BF>(zv[0], zv[1]);
+                        spk[d] = pack2<BF>(sv[0], sv[1]);
+                    }
+                    zf[2 * hf + j][0] = __builtin_bit_cast(V8, u32x4{zpk[0], zpk[1], zpk[2], zpk[3]});
+                    zf[2 * hf + j][1] = __builtin_bit_cast(V8, u32x4{zpk[4], zpk[5], zpk[6], zpk[7]});
+                    if constexpr (TRAIN) {
+                        store_tile(a.z, tile, zpk);
+                        store_tile(a.sg, tile, spk);
+                    } else {
+                        if (keep_z) store_tile(a.z, tile, zpk);   // (not counted by the waits: they are only stricter for it)
                     }
                 }
-            }
+            };
+            if (ragged_co) epilogue(std::true_type{});
+            else epilogue(std::false_type{});
+            stamp(2 + hf);
         }(), ...);
-    }(std::integer_sequence<int, 0, 1>{});
+    }(std::make_integer_sequence<int, NGH>{});
+    // stores of the LAST gate epilogue when z and sg are both kept: 4 per tile
+    constexpr int LAST_TILES = NZT - 2 * (NGH - 1) >= 2 ? 2 : 1;
 
     // ---- res phase: r = [W_res | W_proj] [z ; x(t)] ---------------------------------------------------------------------------------
     if (a.do_res) {
-        V8 xp[8];                                             // x(t): the projection's B operand (often no tap has offset 0)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks < a.nci16 && active) xp[ks] = *reinterpret_cast<const V8*>(xb + (long long)(2 * ks) * ld * 16 + hld);
-            else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xp[ks][j] = 0;
-            }
-        }
         init_acc(2);
+        constexpr int PREV = TRAIN ? 4 * LAST_TILES : 0;
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (stage(WN_EXTRA(S, PREV), zf[S][0], zf[S][1]), ...);
+        }(std::make_integer_sequence<int, NZT>{});
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (stage(WN_EXTRA(NZT + S, PREV), xp[2 * S], xp[2 * S + 1]), ...);
+        }(std::make_integer_sequence<int, NZT>{});
+        stamp(4);
+        const float orr = a.osc_res;
+        unsigned ovf = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < a.nzt) stage(zf[j][0], zf[j][1]);
+        for (int m = 0; m < NZT; ++m) {
+            unsigned pk[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (2 * s < a.nci16) stage(xp[2 * s], xp[2 * s + 1]);
-        if (active) {
-            const float orr = a.osc_res;
-            unsigned ovf = 0;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < a.nzt) {
-                    unsigned pk[8];
-#pragma unroll
-                    for (int d = 0; d < 8; ++d) {
-                        const float v0 = acc[m][2 * d] * orr, v1 = acc[m][2 * d + 1] * orr;
-                        if constexpr (!BF) ovf |= (!(__builtin_fabsf(v0) <= 65504.0f) || !(__builtin_fabsf(v1) <= 65504.0f)) ? 1u : 0u;
-                        pk[d] = pack2<BF>(v0, v1);
-                    }
-                    store_tile(a.r, m, pk);
-                }
+            for (int d = 0; d < 8; ++d) {
+                const float v0 = acc[m][2 * d] * orr, v1 = acc[m][2 * d + 1] * orr;
+                if constexpr (!BF) ovf |= (!(__builtin_fabsf(v0) <= 65504.0f) || !(__builtin_fabsf(v1) <= 65504.0f)) ? 1u : 0u;
+                pk[d] = pack2<BF>(v0, v1);
             }
-            if constexpr (!BF) {
-                if (ovf && a.flag) atomicOr(a.flag, 1u);
-            }
+            store_tile(a.r, m, pk);
         }
+        if constexpr (!BF) {
+            if (ovf && a.flag && col_ok) atomicOr(a.flag, 1u);
+        }
+        stamp(5);
     }
 
     // ---- skip phase (inference): S (+)= W_skip' z + b' ------------------------------------------------------------------------------
-    if (a.do_skip) {
-        init_acc(3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < a.nzt) stage(zf[j][0], zf[j][1]);
-        if (active) {
+    if constexpr (SKIP) {
+        if (a.do_skip) {
+            init_acc(3);
+            // (stores of earlier epilogues are not counted here: stricter waits, an inference-only phase)
+            [&]<int... S>(std::integer_sequence<int, S...>) {
+                (stage(WN_EXTRA(S, 0), zf[S][0], zf[S][1]), ...);
+            }(std::make_integer_sequence<int, NZT>{});
             const float os = a.osc_skip;
-            float* sp = a.skip + ((long long)b * a.skip_rows + 4 * h) * a.L + t;
+            // wave-uniform row base in SGPRs + one 32-bit per-lane offset: no vector address arithmetic per access
+            float* const ubase = a.skip + ((long long)b * a.skip_rows) * a.L + t0;
+            const int loff = 4 * h * a.L + r;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -265,25 +297,73 @@ __global__ __launch_bounds__(256, 2) void hfused_fwd_kernel(const HFusedArgs a) 
                     const int row0 = 32 * m + 8 * i + 4 * h;          // rows row0 .. row0 + 3
                     float old[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        old[q] = (a.skip_accum && col_ok && row0 + q < a.skip_rows) ? sp[(long long)(32 * m + 8 * i + q) * a.L] : 0.0f;
+                    for (int q = 0; q < 4; ++q) {
+                        float* u = ubase + (long long)(32 * m + 8 * i + q) * a.L;
+                        old[q] = (a.skip_accum && col_ok && row0 + q < a.skip_rows) ? u[loff] : 0.0f;
+                    }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col_ok && row0 + q < a.skip_rows) sp[(long long)(32 * m + 8 * i + q) * a.L] = acc[m][4 * i + q] * os + old[q];
+                    for (int q = 0; q < 4; ++q) {
+                        float* u = ubase + (long long)(32 * m + 8 * i + q) * a.L;
+                        if (col_ok && row0 + q < a.skip_rows) u[loff] = acc[m][4 * i + q] * os + old[q];
+                    }
                 }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the surplus stages of the ring land before the LDS is released
+    stamp(7);
+    if (a.stamps && wave == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.stamps[(long long)blockIdx.x * 8 + i] = tstamp[i];
+    }
+    #undef WN_EXTRA
 }
 
-hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st) {
-    if (a.nunit <= 0 || a.nstage <= 0) return hipSuccess;
+unsigned long long* g_fused_stamps = nullptr;
+int g_fused_stamp_wgs = 0;
+
+hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a_in, hipStream_t st) {
+    if (a_in.nunit <= 0 || a_in.nstage <= 0) return hipSuccess;
+    HFusedArgs a = a_in;
+    static const int dbg = getenv("WN_FUSED_DBG") ? atoi(getenv("WN_FUSED_DBG")) : 0;   // measurement: 1 no stores, 2 no tanh/sigmoid, 4 no MFMA
+    a.dbg = dbg;
+    static unsigned long long* stamps = nullptr;   // measurement (WN_FUSED_STAMPS=1): per-workgroup phase stamps, read back by wn_debug_fused_stamps
+    static const bool want = getenv("WN_FUSED_STAMPS") != nullptr;
+    if (want) {
+        if (!stamps) (void)hipMalloc(&stamps, sizeof(unsigned long long) * 8 * 65536);
+        a.stamps = stamps;
+        g_fused_stamps = stamps;
+        g_fused_stamp_wgs = ((a.nunit + 3) / 4 + 7) / 8 * 8;
+    }
     const int nwg = (a.nunit + 3) / 4;
     const unsigned grid = (unsigned)(((nwg + 7) / 8) * 8);
-    if (prec == HP_BF16) hipLaunchKernelGGL((hfused_fwd_kernel<true>), dim3(grid), dim3(256), 0, st, a);
-    else if (prec == HP_F16) hipLaunchKernelGGL((hfused_fwd_kernel<false>), dim3(grid), dim3(256), 0, st, a);
-    else return hipErrorInvalidValue;
+    const bool bf = prec == HP_BF16;
+    if (prec != HP_BF16 && prec != HP_F16) return hipErrorInvalidValue;
+    const int mode = a.sg.base == nullptr ? 1 : (a.do_skip ? 2 : 0);   // sg stored <=> z stored (the API layer checks)
+#define WN_LAUNCH_FUSED(N)                                                                                    \
+    do {                                                                                                      \
+        if (bf && mode == 0) hipLaunchKernelGGL((hfused_fwd_kernel<true, N, 0>), dim3(grid), dim3(256), 0, st, a);       \
+        else if (bf && mode == 1) hipLaunchKernelGGL((hfused_fwd_kernel<true, N, 1>), dim3(grid), dim3(256), 0, st, a);  \
+        else if (bf) hipLaunchKernelGGL((hfused_fwd_kernel<true, N, 2>), dim3(grid), dim3(256), 0, st, a);               \
+        else if (mode == 0) hipLaunchKernelGGL((hfused_fwd_kernel<false, N, 0>), dim3(grid), dim3(256), 0, st, a);       \
+        else if (mode == 1) hipLaunchKernelGGL((hfused_fwd_kernel<false, N, 1>), dim3(grid), dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((hfused_fwd_kernel<false, N, 2>), dim3(grid), dim3(256), 0, st, a);                      \
+    } while (0)
+    switch (a.nzt) {
+        case 1: WN_LAUNCH_FUSED(1); break;
+        case 2: WN_LAUNCH_FUSED(2); break;
+        case 3: WN_LAUNCH_FUSED(3); break;
+        case 4: WN_LAUNCH_FUSED(4); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef WN_LAUNCH_FUSED
     return hipGetLastError();
 }
 
 }  // namespace wn
+// measurement only (tools/fused_stamps.py; not in include/wavenet_amd.h): copy the phase stamps of the last fused launch
+extern "C" int wn_debug_fused_stamps(unsigned long long* host, int max_wgs) {
+    if (!wn::g_fused_stamps) return 0;
+    const int n = wn::g_fused_stamp_wgs < max_wgs ? wn::g_fused_stamp_wgs : max_wgs;
+    if (hipMemcpy(host, wn::g_fused_stamps, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}

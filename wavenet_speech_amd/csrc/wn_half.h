@@ -163,12 +163,15 @@ struct HFusedArgs {
     HDst z, sg, r;              // base == nullptr: not stored
     float* skip;                // dense fp32 [B][skip_rows][L] (inference) or nullptr
     unsigned* flag;
+    char* dump;                 // 1 KiB that masked store lanes write to (so that every store instruction is issued by every wave)
     int xunit[kFMaxGateK];      // 16-byte unit offset of gate k-step kk = (tap j, channels 16 ks ..): (2 ks) * ld + tap offset
     int nkg, nci16, nzt, co;    // gate k-steps; round_up(Ci, 32) / 16; z tiles of 32 channels; valid z channels
     int do_res, do_skip, skip_rows, skip_accum;
     int jump_at, jump;          // stream stages >= jump_at are `jump` stages further on (res phase not run)
     float osc_gate, osc_res, osc_skip;
     int B, L, ld, halo, units_per_row, nunit, nstage;
+    int dbg;                    // measurement only (WN_FUSED_DBG)
+    unsigned long long* stamps; // measurement only (WN_FUSED_STAMPS): 8 s_memtime stamps per workgroup
 };
 hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st);
 

@@ -135,7 +135,7 @@ struct HFusedPlan {
     int st_gate = 0, st_res = 0, st_skip = 0;     // ring stages (32 channels of K x 128 rows) per gate half / res / skip phase
     size_t off_w = 0, off_bias = 0;
     int stages() const { return ngh * st_gate + st_res + st_skip; }
-    size_t bytes() const { return on ? align256((size_t)stages() * kFStageBytes) + align256(4 * kFRows * sizeof(float)) : 0; }
+    size_t bytes() const { return on ? align256((size_t)stages() * kFStageBytes) + align256(4 * kFRows * sizeof(float)) + 1024 : 0; }   // + dump line
 };
 
 bool fused_forward_enabled() {
@@ -195,7 +195,8 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
         HFusedPlan& f = p.fu;
         f.nci16 = cp32(Ci) / 16; f.nzt = cp32(Co) / 32; f.nkg = k * f.nci16; f.ngh = (f.nzt + 1) / 2;
         f.st_gate = f.nkg / 2; f.st_res = f.nzt + f.nci16 / 2; f.st_skip = f.nzt;
-        f.on = fused_forward_enabled() && P == 1 && cp32(Ci) <= 128 && cp32(Co) <= 128 && Ms <= 128 && f.nkg <= kFMaxGateK;
+        // (two taps and equally padded channel counts: the kernel is instantiated per z-tile count with every loop bound a constant)
+        f.on = fused_forward_enabled() && P == 1 && k == 2 && cp32(Ci) == cp32(Co) && cp32(Co) <= 128 && Ms <= 128 && f.nkg <= kFMaxGateK;
     }
     // a block that runs the fused forward packs no separate gate / res / skip weights
     p.off_fa = 0;
@@ -453,31 +454,40 @@ int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params
     return WN_OK;
 }
 
+int wn_hblock_forward_is_fused(const wn_block_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hblock(s, precision, off) != WN_OK) return 0;
+    return plan_hblock(s, precision).fu.on ? 1 : 0;
+}
+
 int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed, const void* x, void* r_out,
                       float* skip_dense, int skip_accumulate, void* sg, void* z, unsigned* overflow_flag,
                       wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
-    if (!packed || !x || !z) return WN_ERR_NULL;
+    if (!packed || !x) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const HBlockPlan bp = plan_hblock(s, precision);
     const int P = hp_planes(precision);
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
     const double BL = (double)s->batch * s->length;
+    const bool fused = bp.fu.on;
+    if (!z && !(fused && !sg)) return WN_ERR_NULL;            // z may be omitted only where the fused inference form runs
     const HView vx = view(x, Ci, s->ld, P), vz = view(z, Co, s->ld, P);
-    if (bp.fu.on) {
+    if (fused) {
         const HFusedPlan& f = bp.fu;
         HFusedArgs fa;
         std::memset(&fa, 0, sizeof(fa));
         fa.wstream = (const char*)packed + f.off_w;
         fa.bias = reinterpret_cast<const float*>((const char*)packed + f.off_bias);
         fa.x = vx.base; fa.x_ustride = vx.ustride;
-        fa.z = dst_of(vz);
+        if (z) fa.z = dst_of(vz);
         if (sg) fa.sg = dst_of(view(sg, Co, s->ld, P));
         if (r_out) fa.r = dst_of(view(r_out, Co, s->ld, P));
         fa.skip = skip_dense; fa.skip_rows = Ms; fa.skip_accum = skip_accumulate ? 1 : 0;
         fa.flag = overflow_flag;
+        fa.dump = (char*)packed + f.off_bias + align256(4 * kFRows * sizeof(float));
         for (int j = 0; j < k; ++j)
             for (int ks = 0; ks < f.nci16; ++ks) fa.xunit[j * f.nci16 + ks] = 2 * ks * s->ld + off[j];
         fa.nkg = f.nkg; fa.nci16 = f.nci16; fa.nzt = f.nzt; fa.co = Co;

@@ -220,6 +220,8 @@ class _HalfStackFn(torch.autograd.Function):
             r = _hlease(mode, B, spec.co, layout, dev) if l + 1 < n else None
             if training:
                 sg, z = (_hlease(mode, B, spec.co, layout, dev) for _ in range(2))   # kept for backward; tanh = z / sg
+            elif lib.wn_hblock_forward_is_fused(ctypes.byref(shape), mode.code):
+                sg = z = None                  # inference through the fused kernel: z stays on the chip
             else:
                 sg = None
                 if zbuf is None or zbuf.channels != spec.co:
