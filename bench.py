@@ -45,7 +45,7 @@ SUSTAINED_NOTE = ("1600 TFLOP/s = what back-to-back v_mfma_f32_32x32x16_f16 issu
                   "the cycle count at a DVFS-held 1.75 GHz; tools/probes/hwgrad_loop.hip, profiles/r02/half_tuning.txt item 11); "
                   "streaming the operands from HBM beside it lowers the clock further (1.53 GHz in the same model)")
 PEAK_HBM_GBS = 8000.0           # HBM3E spec peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 # BASELINE.json configs -> workloads.  cfg3 is the configuration the metric is quoted on; the others are parity-test
 # cases that can be timed with the same harness (their lines are committed under profiles/, they are not the headline).
@@ -230,58 +230,71 @@ def cpu_baseline(args, budget_s=12.0):
                       % (torch.__version__, args.model, channels, len(layers), L_s, seq_len, len(times), best)}
 
 
-# timing classes of the library (wn_prof_*) -> the code-object symbol rocprofv3 reports them under.  The four block GEMMs
-# and the conv / skips_sum launches are instantiations of ONE template; res, dx, skips_sum and the plain convs share the
-# EPI_LINEAR instantiation, so rocprofv3 --stats lists them as one kernel (the largest line of the table).
+# timing classes of the library (wn_prof_*) -> the code-object symbol class rocprofv3 reports them under.  The four block
+# GEMMs and the conv / skips_sum launches are instantiations of ONE template; res, dx, skips_sum and the plain convs share the
+# EPI_LINEAR instantiation, so rocprofv3 --stats lists them as one kernel.
 SYMBOL_OF = {
     "series_gemm_kernel<res>": "linear", "series_gemm_kernel<dx>": "linear", "series_gemm_kernel<conv_fwd>": "linear",
     "series_gemm_kernel<conv_bwd_data>": "linear", "series_gemm_kernel<skips_sum>": "linear",
     "series_gemm_kernel<gate>": "gate", "series_gemm_kernel<dz,dgate>": "dgate", "wgrad_kernel": "wgrad",
-    "hgemm_kernel<gate>": "hgate", "hgemm_kernel<res>": "hlinear", "hgemm_kernel<dz,dgate>": "hdgate",
-    "hgemm_kernel<dx>": "hlinear", "hgemm_kernel<skips_sum>": "hlinear", "hwgrad_kernel": "hwgrad",
+    "hgemm_kernel<gate>": "hgate", "hgemm_kernel<res>": "hstore", "hgemm_kernel<dz,dgate>": "hdgate",
+    "hgemm_kernel<dx>": "hstore", "hgemm_kernel<skips_sum>": "hf32", "hgemm_kernel<conv_fwd>": "hf32",
+    "hgemm_kernel<conv_bwd_data>": "hf32", "hwgrad_kernel": "hwgrad", "hfused_fwd_kernel": "hfused",
 }
+# class -> regex on the demangled kernel name.  Template arguments: series_gemm_kernel<MT, NT, EPI, PFB, WPS>,
+# hgemm_kernel<MT, P, BF, EPI>, hgemm8_kernel<P, BF, EPI, NT, WR>, hfused_fwd_kernel<BF, NZT, MODE>
 SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm_kernel<\d+, \d+, 1,",
              "dgate": r"series_gemm_kernel<\d+, \d+, 2,", "wgrad": r"(?<![a-z])wgrad_kernel<",
-             "hlinear": r"hgemm_kernel<\d+, \d+, \w+, [03]>", "hgate": r"hgemm8?_kernel<(?:\d+, )?\d+, \w+, 1>",
-             "hdgate": r"hgemm8?_kernel<(?:\d+, )?\d+, \w+, 2>",
-             "hwgrad": r"hwgrad_kernel<"}
-SYMBOL_NAME = {"linear": "series_gemm_kernel<4, 4, 0, 3, 1>  [EPI_LINEAR: res, dx, skips_sum, conv launches]",
-               "gate": "series_gemm_kernel<4, 4, 1, 3, 1>  [EPI_GATE]", "dgate": "series_gemm_kernel<4, 4, 2, 3, 1>  [EPI_DGATE: dz]",
-               "wgrad": "wgrad_kernel<4>", "hlinear": "hgemm_kernel [EPI_LINEAR: res, dx, skips_sum]",
-               "hgate": "hgemm8_kernel / hgemm_kernel [EPI_GATE]", "hdgate": "hgemm_kernel [EPI_DGATE: dz]", "hwgrad": "hwgrad_kernel"}
+             "hstore": r"hgemm_kernel<\d+, \d+, \w+, 0>|hgemm8_kernel<\d+, \w+, 0,", "hgate": r"hgemm_kernel<\d+, \d+, \w+, 1>|hgemm8_kernel<\d+, \w+, 1,",
+             "hdgate": r"hgemm_kernel<\d+, \d+, \w+, 2>|hgemm8_kernel<\d+, \w+, 2,",
+             "hf32": r"hgemm_kernel<\d+, \d+, \w+, 3>|hgemm8_kernel<\d+, \w+, 3,",
+             "hwgrad": r"hwgrad_kernel<", "hfused": r"hfused_fwd_kernel<"}
+SYMBOL_NOTE = {"linear": "EPI_LINEAR: res, dx, skips_sum, conv launches", "gate": "EPI_GATE", "dgate": "EPI_DGATE: dz", "wgrad": "",
+               "hstore": "HEPI_STORE: res, dx", "hgate": "HEPI_GATE", "hdgate": "HEPI_DGATE: dz", "hf32": "HEPI_F32: skips_sum, convs",
+               "hwgrad": "", "hfused": "gate -> z -> res [+ skip] in one launch"}
 
 
-def pmc_table(name):
+def profile_dir(args):
+    """profiles/<round>/<config>_<precision>/ : the committed rocprofv3 summaries of THIS configuration and precision (collected
+    by tools/collect_profiles.sh); other configurations' counters are never quoted."""
+    return os.path.join(ROOT, "profiles", PROFILE_ROUND, "%s_%s" % (args.config, args.precision))
+
+
+def _read_csv(path):
     import csv
-    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, name)
     if not os.path.exists(path):
-        return None, None
-    return list(csv.DictReader(open(path))), os.path.relpath(path, ROOT)
+        return None
+    return list(csv.DictReader(open(path)))
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of a kernel symbol from the committed PMC summary (None if absent)."""
+def instantiation_of(args, symbol):
+    """the exact instantiation (demangled name) of a kernel class that dominates this configuration: the row of the class with the
+    largest total time in the committed rocprofv3 --stats table of this (config, precision); None without such a table"""
+    import glob
     import re
-    rows, path = pmc_table("pmc_hbm_traffic.csv")
-    if symbol not in SYMBOL_RE or not rows:
-        return None, None
-    total = 0.0
-    for row in rows:
-        if re.search(SYMBOL_RE[symbol], row["kernel"]):
-            total += float(row["avg_bytes_corrected"])
-    return (total or None), path
+    best = None
+    for path in sorted(glob.glob(os.path.join(profile_dir(args), "kernel_stats*.csv"))):
+        for row in _read_csv(path) or []:
+            if symbol in SYMBOL_RE and re.search(SYMBOL_RE[symbol], row["Name"]):
+                t = float(row["TotalDurationNs"])
+                if best is None or t > best[0]:
+                    best = (t, row["Name"], float(row["AverageNs"]) * 1e-6, os.path.relpath(path, ROOT))
+    return best
 
 
-def pmc_mfma_busy(symbol):
-    """MFMA-busy fraction of a kernel symbol from the committed PMC summary (None if absent)."""
-    import re
-    rows, path = pmc_table("pmc_mfma.csv")
-    if symbol not in SYMBOL_RE or not rows:
+def pmc_lookup(args, name, exact_kernel, column):
+    """`column` of the row whose kernel name equals `exact_kernel` in profiles/<round>/<config>_<precision>/<name>; (None, None) if the
+    file or the row is missing"""
+    path = os.path.join(profile_dir(args), name)
+    rows = _read_csv(path)
+    if not rows or exact_kernel is None:
         return None, None
+    total, hit = 0.0, False
     for row in rows:
-        if re.search(SYMBOL_RE[symbol], row["kernel"]):
-            return float(row["mfma_busy_frac"]), path
-    return None, path
+        if row["kernel"].strip() == exact_kernel.strip():
+            total += float(row[column])
+            hit = True
+    return (total if hit else None), (os.path.relpath(path, ROOT) if hit else None)
 
 
 def main():
@@ -574,24 +587,35 @@ def main():
         dom = max(by_symbol, key=lambda k: by_symbol[k][0])
         ms, n, fl = by_symbol[dom]
         ach = nprod * fl / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom)
-        busy, busy_src = pmc_mfma_busy(dom)
-        roofline = {"kernel": SYMBOL_NAME[dom] if C > 64 else dom, "bound": "mfma", "achieved": round(ach, 2),
+        inst = instantiation_of(args, dom)                      # (total ns, exact demangled name, avg ms, source) or None
+        exact = inst[1] if inst else None
+        traffic, traffic_src = pmc_lookup(args, "pmc_hbm_traffic.csv", exact, "avg_bytes_corrected")
+        busy, busy_src = pmc_lookup(args, "pmc_mfma.csv", exact, "mfma_busy_frac")
+
+        def label(k):
+            note = SYMBOL_NOTE.get(k, "")
+            i = instantiation_of(args, k)
+            return (i[1] if i else k) + ("  [" + note + "]" if note else "")
+        roofline = {"kernel": label(dom), "bound": "mfma", "achieved": round(ach, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
-                                    "separate passes, from %s (committed summary of tools/collect_profiles.sh at the default "
-                                    "configuration, not collected live)" % traffic_src,
+                    "traffic_unit": "HBM bytes per launch of exactly this instantiation: rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + "
+                                    "WRITE_SIZE, separate passes, from %s (committed summary of tools/collect_profiles.sh for THIS "
+                                    "configuration and precision; null when no such capture is committed -- not collected live)" % traffic_src,
                     "mfma_busy_frac": busy, "mfma_busy_src": busy_src,
+                    "rocprof_avg_launch_ms": round(inst[2], 4) if inst else None, "rocprof_src": inst[3] if inst else None,
                     "avg_launch_ms": round(ms / n, 4), "launches": n, "flops_per_launch": fl / n,
                     "mfma_products_per_algorithmic_product": nprod,
                     "share_of_step": round(ms / args.steps / (step_s * 1e3), 4),
-                    "other_symbols": {SYMBOL_NAME[k] if C > 64 else k:
+                    "other_symbols": {label(k):
                                       {"avg_launch_ms": round(v[0] / v[1], 4),
                                        "tflops": round(nprod * v[2] / (v[0] * 1e-3) / 1e12, 2),
                                        "frac": round(nprod * v[2] / (v[0] * 1e-3) / 1e12 / peak, 4),
                                        "share_of_step": round(v[0] / args.steps / (step_s * 1e3), 4)}
                                       for k, v in by_symbol.items() if k != dom}}
+        if traffic is not None:
+            # algorithmic bytes per (utterance, time step, block) = 8 C s for the whole fwd+bwd of a block
+            roofline["traffic_vs_block_algorithmic_bytes"] = round(traffic / (8.0 * C * esz * float(B) * L_eff), 3)
         if peak == PEAK_HALF_MFMA_TFLOPS:
             roofline["frac_of_sustained"] = round(ach / SUSTAINED_HALF_MFMA_TFLOPS, 4)
             roofline["sustained_note"] = SUSTAINED_NOTE
@@ -650,6 +674,16 @@ def main():
     os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    # leave nothing running (one process outlived BENCH_r02): this process starts no children at N = 1; say so, and
+    # end any a library may have started behind our back
+    try:
+        import psutil
+        kids = psutil.Process().children(recursive=True)
+        log("child processes at exit: %d%s" % (len(kids), (" " + str([k.name() for k in kids])) if kids else ""))
+        for k in kids:
+            k.terminate()
+    except Exception as e:   # psutil missing: nothing to report
+        log("child-process check skipped: %s" % e)
 
 
 if __name__ == "__main__":

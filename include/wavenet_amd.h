@@ -187,17 +187,13 @@ int wn_nll_backward(const float* logits, const long long* target, const float* l
 /* ---- entry conv on quantised levels: replaces entry_conv1d(one_hot(levels)) of
  * modules/wavenet.py:54,93 + modules/fns.py:6-15 without materialising the [B][classes][L] one-hot.
  *   forward : y[b][co][t] = bias[co] + sum_j W[co][levels[b][t + j - (k-1)]][j]   (causal, dilation 1; y dense [B][Co][L])
- *   backward: dW[co][c][j] = sum over (b,t) with levels[b][t + j - (k-1)] == c of dy[b][co][t];  db = row sums of dy.
- *             Deterministic: per-slab partial tables reduced in slab order (no float atomics).
+ *   backward: no entry point of its own: dW[co][c][j] = sum over (b,t) with levels[b][t + j - (k-1)] == c of dy[b][co][t] is
+ *             formed by wn_conv_backward_weights against a one-hot the caller builds for the duration of the backward call
+ *             (the host mirror does; a gather-form kernel without it was measured 3.5x slower and removed in round 3).
  * levels: [B][L] int64 in [0, classes); anything else is counted in *bad_levels (DEVICE int, caller-zeroed, may be NULL)
  * and contributes nothing.  classes <= 512. */
 int wn_embed_forward(const long long* levels, const float* weight, const float* bias, float* y, int batch, int length,
                      int classes, int out_channels, int kernel_width, int* bad_levels, wn_stream_t stream);
-size_t wn_embed_workspace_bytes(int batch, int length, int classes, int out_channels, int kernel_width);
-int wn_embed_backward(const long long* levels, const float* dy, float* dweight, float* dbias /* may be NULL */, void* workspace,
-                      size_t workspace_bytes, int batch, int length, int classes, int out_channels, int kernel_width,
-                      wn_stream_t stream);
-
 /* ---- synthetic reads on the device: the reference's on-line generator
  * utils/gaussian_kmer_model.py:53-104 (gaussian_model_fn :53-73, quantize_fn :79-86, one_hot_fn :89-97), float64 like its
  * numpy arithmetic.  All pointers are DEVICE pointers.

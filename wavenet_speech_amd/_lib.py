@@ -110,9 +110,6 @@ SIGNATURES = {
     "wn_hconv_backward_weights": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_float, c_float_p, c_float_p, c_float_p,
                                           c_void_p, c_size_t, c_void_p]),
     "wn_embed_forward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "wn_embed_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "wn_embed_backward": (c_int, [c_void_p, c_float_p, c_float_p, c_float_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
-                                  c_int, c_void_p]),
     "wn_synth_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wn_synth_bases": (c_int, [c_ulonglong, c_int, c_int, c_void_p, c_void_p]),
     "wn_synth_signal": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ulonglong, c_void_p, c_void_p,

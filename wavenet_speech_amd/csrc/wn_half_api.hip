@@ -265,7 +265,7 @@ inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
 
 // profiling classes shared with wn_api.hip (same table, same order)
 enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
-       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED };
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA };
 
 }  // namespace
 
@@ -691,7 +691,7 @@ int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_para
     if (!half_prec(precision)) return WN_ERR_UNSUPPORTED;
     if (table_bytes < wn_hstack_pack_table_bytes(nblocks)) return WN_ERR_WORKSPACE;
     std::vector<HPackArgs> jobs;
-    size_t total = 0;
+    size_t total = 256;                 // (offsets travel as pointers through the job builders: 0 would read as NULL)
     for (int l = 0; l < nblocks; ++l) {
         int off[WN_MAX_TAPS];
         int rc = check_hblock(&shapes[l], precision, off);
@@ -1066,7 +1066,7 @@ int wn_hconv_forward(const wn_conv_shape* s, int precision, const void* packed, 
     const HView vx = view(x, Ci, s->ld, P);
     for (int j = 0; j < k; ++j) set_hseg(a, j, vx, off[j], cp.f.seg_nks[j]);
     a.out32 = y_dense; a.out32_rows = Co; a.out32_accum = 0;
-    wn::ProfScopeShared prof(KC_CONV_FWD, 2.0 * Co * (double)(k * Ci) * (double)s->batch * s->length, st);
+    wn::ProfScopeShared prof(KC_HCONV_FWD, 2.0 * Co * (double)(k * Ci) * (double)s->batch * s->length, st);
     WN_HIP(launch_hgemm(precision, cp.f.kernel(), HEPI_F32, a, st), "hgemm<conv>");
     return WN_OK;
 }
@@ -1086,7 +1086,7 @@ int wn_hconv_backward_data(const wn_conv_shape* s, int precision, const void* pa
     const HView vdy = view(dy, Co, s->ld, P);
     for (int j = 0; j < k; ++j) set_hseg(a, j, vdy, -off[j], cp.kb.seg_nks[j]);
     a.out32 = dx_dense; a.out32_rows = Ci; a.out32_accum = 0; a.dyn_inv = dyn_inv_scale;
-    wn::ProfScopeShared prof(KC_CONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
+    wn::ProfScopeShared prof(KC_HCONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
     WN_HIP(launch_hgemm(precision, cp.kb.kernel(), HEPI_F32, a, st), "hgemm<conv dx>");
     return WN_OK;
 }

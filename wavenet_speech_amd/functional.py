@@ -493,20 +493,16 @@ class _EmbedConvFn(torch.autograd.Function):
         dy = d_y.contiguous()
         dw = torch.empty(Co, classes, k, dtype=torch.float32, device=dev)
         db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.has_bias else None
-        if os.environ.get("WN_EMBED_BACKWARD", "gemm") == "gather":
-            # per-class segmented sums straight from the levels: never builds a one-hot, deterministic, but instruction-bound
-            # (1.95 ms at 16 x 256 x 16000 against 0.55 ms below)
-            ws_bytes = lib.wn_embed_workspace_bytes(B, L, classes, Co, k)
-            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-            _lib.check(lib.wn_embed_backward(_p(q), _p(dy), _p(dw), _p(db), _p(ws), ws_bytes, B, L, classes, Co, k, _stream()),
-                       "wn_embed_backward")
-            return dw, db, None, None
-        # default: the exact-fp32 weight-gradient GEMM (wgrad_kernel, fixed summation order) against a one-hot that exists only
-        # inside this call -- the forward pass and the saved state never hold one
+        # the exact-fp32 weight-gradient GEMM (wgrad_kernel, fixed summation order) against a one-hot that exists only inside this
+        # call: backward DOES materialise a one-hot (279 MB at 16 x 256 x 16000, from the lease pool); the forward pass and the
+        # saved state never hold one.  (A gather-form kernel without it was 3.5x slower and was removed: csrc/wn_embed.hip.)
         layout = SeriesLayout(L, k - 1)
         shape = _lib.ConvShape(B, L, classes, Co, k, 1, 1, layout.ld, layout.halo)
         xin = Lease(B, classes, layout, dev)
-        window(xin.t, classes, layout).zero_().scatter_(1, q.unsqueeze(1), 1.0)
+        # a level outside [0, classes) was counted by the forward kernel (and raises, one call late in training calls): here it must
+        # not become an out-of-bounds scatter (ROCm builds compile the index assert out) -- it contributes nothing, like in the kernels
+        ok = (q >= 0) & (q < classes)
+        window(xin.t, classes, layout).zero_().scatter_(1, q.clamp(0, classes - 1).unsqueeze(1), ok.unsqueeze(1).to(torch.float32))
         dyl = Lease(B, Co, layout, dev)
         load_series(dyl.t, dy, layout)
         ws_bytes = lib.wn_conv_wgrad_workspace_bytes(ctypes.byref(shape))

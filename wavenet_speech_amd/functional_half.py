@@ -128,9 +128,11 @@ class StackPackTable(object):
         ngroups = (n + _lib.MAX_STACK_GROUP - 1) // _lib.MAX_STACK_GROUP
         soffs = (ctypes.c_size_t * ngroups)()
         total, njobs, nblocks = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0)
-        _lib.check(lib.wn_hstack_pack_table_build(shapes, params, n, mode.code, 1 if skipsum else 0, dyn, len(storages), host, nbytes,
-                                                  offs, soffs, ctypes.byref(total), ctypes.byref(njobs), ctypes.byref(nblocks)),
-                   "wn_hstack_pack_table_build")
+        rc = lib.wn_hstack_pack_table_build(shapes, params, n, mode.code, 1 if skipsum else 0, dyn, len(storages), host, nbytes,
+                                            offs, soffs, ctypes.byref(total), ctypes.byref(njobs), ctypes.byref(nblocks))
+        if rc == -2:
+            raise NotImplementedError("layout not covered by the pack-job table")   # WN_ERR_UNSUPPORTED: per-block packing instead
+        _lib.check(rc, "wn_hstack_pack_table_build")
         self.table = torch.frombuffer(host, dtype=torch.uint8).to(device)       # the one host-to-device copy of the table's life
         self.nblk, self.njobs, self.launch_blocks, self.ndyn = n, njobs.value, nblocks.value, len(storages)
         self.block_offsets = list(offs)
@@ -191,7 +193,7 @@ class _HalfStackFn(torch.autograd.Function):
                 if table is None:
                     try:
                         table = StackPackTable(lib, specs, mode, B, layout, prepped, storages, training, dev)
-                    except RuntimeError:
+                    except NotImplementedError:
                         table = False          # e.g. skip biases that are not equally spaced: per-block packing
                     if len(pack_cache.tables) >= 8:
                         pack_cache.tables.clear()
