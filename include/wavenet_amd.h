@@ -292,6 +292,34 @@ int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const voi
                                const void* dg, const void* dr, const void* dskip, const wn_block_params* grads,
                                const float* dyn_inv_scale, void* workspace, size_t workspace_bytes, wn_stream_t stream);
 
+/* The convolutions AROUND the block stack kept in the half series (the callers either side of the path; reference
+ * modules/wavenet.py:67-71,103 output_stack, raw_ctcnet.py:57-61,89-93,128,148 feature_layer / output_block): LeakyReLU and the
+ * 1x1 convs run without dense fp32 round trips between them.
+ *   wn_hskipsum_forward_series     out = leaky(skips_sum) * out_scale as a half series (instead of the dense fp32 of
+ *                                  wn_hskipsum_forward): the activated input of the output block's first conv
+ *   wn_hconv_forward_series        y = leaky(conv(x) + b) * out_scale, series in, series out (leaky_slope 1 = no activation)
+ *   wn_hconv_backward_data_series  dx = (W^T dy) * leaky'(act): act = the conv's stored (activated) input, NULL = no activation
+ * Weight gradients: wn_hconv_backward_weights (series operands already).  out_scale is the scale the stored tensor carries
+ * (wn_hseries_residual_scale() by convention, so that fp16 cannot overflow); pack the consumer with that input_scale. */
+int wn_hskipsum_forward_series(const wn_skipsum_shape* s, int precision, const void* packed, const void* const* z, void* out_series,
+                               float out_scale, float leaky_slope, unsigned* overflow_flag, wn_stream_t stream);
+int wn_hconv_forward_series(const wn_conv_shape* s, int precision, const void* packed, const void* x, void* y_series, float out_scale,
+                            float leaky_slope, unsigned* overflow_flag, wn_stream_t stream);
+int wn_hconv_backward_data_series(const wn_conv_shape* s, int precision, const void* packed, const void* dy, const void* act,
+                                  float leaky_slope, void* dx_series, unsigned* overflow_flag, wn_stream_t stream);
+
+/* The weight gradients of SEVERAL blocks of one series geometry in one launch (+ one reduction): blocks of <= 128 channels are
+ * two or three gradient tiles each, so per-block launches are short split-K jobs dominated by their partial slabs; keep the
+ * operands of up to wn_hblocks_wgrad_group_max() blocks (after their wn_hblock_backward_data calls) and hand them over
+ * together.  Arrays are indexed by block; dr[l] may be NULL (a last block).  Same results as per-block calls up to the
+ * summation order over time splits (deterministic either way). */
+int wn_hblocks_wgrad_group_max(const wn_block_shape* s, int precision);
+size_t wn_hblocks_wgrad_workspace_bytes(const wn_block_shape* shapes, int nblocks, int precision);
+int wn_hblocks_backward_weights(const wn_block_shape* shapes, int nblocks, int precision, const void* const* x, const void* const* z,
+                                const void* const* da, const void* const* dg, const void* const* dr, const void* const* dskip,
+                                const wn_block_params* grads, const float* dyn_inv_scale, void* workspace, size_t workspace_bytes,
+                                wn_stream_t stream);
+
 /* Every weight-pack job of a stack of blocks in ONE launch.  Training repacks all weights after each optimizer step (five
  * launches per block through wn_hblock_pack, one per group through wn_hskipsum_pack); the jobs' arguments depend only on
  * shapes, precision and pointers, so they are built ONCE into a table: wn_hstack_pack_table_build fills `table_host` (host

@@ -273,7 +273,13 @@ def one_hot_encoding(seq, num_indices):
 
 def capture_leaky_slopes(model):
     """Register forward-pre-hooks on every nn.LeakyReLU of `model`; returns (slopes dict, remove()).  After a forward
-    pass slopes["<module name>"] holds the per-element slope (1 where the input was > 0, else 0.01) on the CPU."""
+    pass slopes["<module name>"] holds the per-element slope (1 where the input was > 0, else 0.01) on the CPU.
+
+    In the half-precision modes the HIP package runs the output block INSIDE its stack function (series layout): the
+    LeakyReLU modules are then never called.  Its un-fused form is bitwise the same forward computation
+    (tests/test_gpu_head.py), so the pattern is taken from one extra no_grad forward in that form (WN_SERIES_HEAD=0),
+    run by a hook on the model itself just before the real, fused forward."""
+    import os
     import torch.nn as nn
     slopes, handles = {}, []
     for name, mod in model.named_modules():
@@ -282,6 +288,25 @@ def capture_leaky_slopes(model):
                 xin = inp[0].detach()
                 slopes[name] = torch.where(xin > 0, torch.ones_like(xin), torch.full_like(xin, ns)).cpu()
             handles.append(mod.register_forward_pre_hook(hook))
+    state = {"busy": False}
+
+    def unfused_first(m, inp):
+        if state["busy"]:
+            return
+        state["busy"] = True
+        old = os.environ.get("WN_SERIES_HEAD")
+        os.environ["WN_SERIES_HEAD"] = "0"
+        try:
+            with torch.no_grad():
+                m(*[t.detach() if isinstance(t, torch.Tensor) else t for t in inp])
+        finally:
+            if old is None:
+                os.environ.pop("WN_SERIES_HEAD", None)
+            else:
+                os.environ["WN_SERIES_HEAD"] = old
+            state["busy"] = False
+    if any(getattr(m, "stack_state", None) is not None for m in model.modules()):
+        handles.append(model.register_forward_pre_hook(unfused_first))
     return slopes, lambda: [h.remove() for h in handles]
 
 

@@ -1,0 +1,61 @@
+"""The output block (LeakyReLU, Conv1d 1x1, LeakyReLU, Conv1d 1x1: reference modules/wavenet.py:67-71, raw_ctcnet.py:89-93) inside
+the half-precision stack function, in the series layout (no dense fp32 skips_sum, no separate LeakyReLU passes), against the
+same block evaluated op by op (WN_SERIES_HEAD=0): the forward results must be bitwise equal -- every scale involved is a power
+of two and the LeakyReLU decisions are taken on the same fp32 accumulators -- and the gradients equal to rounding."""
+import copy
+
+import pytest
+import torch
+
+import wavenet_speech_amd as W
+from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+from wavenet_speech_amd.modules.wavenet import WaveNet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _grads(net, x, cot):
+    for p in net.parameters():
+        p.grad = None
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    (y * cot).sum().backward()
+    return y.detach(), xg.grad, {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f16x3"])
+@pytest.mark.parametrize("model", ["wavenet", "rawctc"])
+def test_series_head_equals_op_by_op_head(precision, model, monkeypatch):
+    torch.manual_seed(5)
+    if model == "wavenet":
+        layers = [(48, 48, 2, d) for d in (1, 2, 4, 8)]
+        net = WaveNet(48, 2, layers, 40, softmax=False).to(DEV)
+        x = torch.randn(2, 48, 530, device=DEV)
+        cot = torch.randn(2, 40, 530, device=DEV)
+    else:
+        layers = [(32, 32, 2, d) for d in (1, 2, 4)]
+        net = RawCTCNet(32, 3, 5, layers, 32, softmax=False, causal=False).to(DEV)
+        x = torch.randn(3, 1, 400, device=DEV)
+        cot = torch.randn(3, 5, 402, device=DEV)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    W.set_precision(net, precision)
+    y1, dx1, g1 = _grads(net, x, cot)
+    with torch.no_grad():
+        y1i = net(x)
+    monkeypatch.setenv("WN_SERIES_HEAD", "0")
+    y0, dx0, g0 = _grads(net, x, cot)
+    assert torch.equal(y1, y0), float((y1 - y0).abs().max())
+    scale = float(y0.abs().max())
+    assert float((y1i - y0).abs().max()) <= 2e-2 * scale        # inference accumulates skips_sum per block: another association
+    # gradients: the two forms choose their power-of-two gradient scales at different points (one for the whole function here, one per
+    # conv there), so hi + lo planes round differently: f16x3's own accuracy (~1e-5 of the largest element), the plain modes' rounding
+    tol = 5e-5 if precision == "f16x3" else 2e-3
+    assert float((dx1 - dx0).abs().max()) <= tol * float(dx0.abs().max())
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            assert float((g1[k] - g0[k]).abs().max()) <= tol * max(float(g0[k].abs().max()), 1e-30), k

@@ -94,6 +94,16 @@ SIGNATURES = {
     "wn_hskipsum_forward": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
     "wn_hblock_backward_data": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_float_p, c_float_p, c_void_p, c_void_p]),
+    "wn_hskipsum_forward_series": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_void_p, c_float, c_float, c_void_p,
+                                           c_void_p]),
+    "wn_hconv_forward_series": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "wn_hconv_backward_data_series": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                              c_void_p]),
+    "wn_hblocks_wgrad_group_max": (c_int, [POINTER(BlockShape), c_int]),
+    "wn_hblocks_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int, c_int]),
+    "wn_hblocks_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                            POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(BlockParams), c_float_p,
+                                            c_void_p, c_size_t, c_void_p]),
     "wn_hstack_pack_table_bytes": (c_size_t, [c_int]),
     "wn_hstack_pack_table_build": (c_int, [POINTER(BlockShape), POINTER(BlockParams), c_int, c_int, c_int, POINTER(MemRange), c_int,
                                            c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),

@@ -49,7 +49,14 @@ struct HDst {               // a half-series destination (or source, for the dga
     int _pad;
 };
 
-enum { HEPI_STORE = 0, HEPI_GATE = 1, HEPI_DGATE = 2, HEPI_F32 = 3 };
+enum { HEPI_STORE = 0, HEPI_GATE = 1, HEPI_DGATE = 2, HEPI_F32 = 3, HEPI_LEAKY = 4 };
+// HEPI_LEAKY: the convolutions around the block stack (feature layer, output block) kept in the half series:
+//   forward  (z.base == nullptr)  y = leaky((acc * oscale + bias) * oscale2)            leaky(v) = v > 0 ? v : leaky * v
+//   backward (z.base = the conv's input activation h = leaky(s), same shape as the output)
+//                                  dx = acc * oscale * (signbit(h) ? leaky : 1)
+//   The stored activation is the mask, read by its SIGN BIT: the forward stores every s <= 0 with the bit set (-0 for s = 0,
+//   LeakyReLU's `x > 0` rule) and a positive s that underflows the format still stores +0 -- a `h > 0` test flipped one
+//   element of 131072 in plain f16 (1/16-scaled activations), which moved a weight gradient by 3e-2 (kink sensitivity).
 
 struct HGemmArgs {
     const char* wpacked;
@@ -63,6 +70,7 @@ struct HGemmArgs {
     const float* dyn_inv;   // HEPI_F32: optional device scalar multiplied into the result (1 / dynamic gradient scale)
     unsigned* flag;         // set to 1 when an fp16 store overflowed (|v| > 65504)
     float oscale;           // accumulators are multiplied by this exact power of two
+    float oscale2, leaky;   // HEPI_LEAKY: scale of the stored result, negative-side slope
     int out32_rows, out32_accum;
     int gate_rows;          // valid channels of the gate epilogues
     int nslab, B, L, ld, halo;
@@ -174,6 +182,7 @@ struct HFusedArgs {
     unsigned long long* stamps; // measurement only (WN_FUSED_STAMPS): 8 s_memtime stamps per workgroup
 };
 hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st);
+static_assert(sizeof(HWgradArgs) <= 4096 && sizeof(HGemmArgs) <= 4096 && sizeof(HFusedArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);
 hipError_t launch_hpack(const HPackArgs& a, hipStream_t st);

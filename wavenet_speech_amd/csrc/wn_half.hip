@@ -546,6 +546,48 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                     }
                 }
             }
+    } else if constexpr (EPI == HEPI_LEAKY) {
+        const HDst d = a.dst[sl.dst];
+        const bool masked = a.z.base != nullptr;
+        const float slope = a.leaky, osc2 = a.oscale2;
+        const long long colo = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+        char* dbase = d.base + (long long)b * d.ustride + colo;
+        const char* mbase = masked ? a.z.base + (long long)b * a.z.ustride + colo : nullptr;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lrow = rowbase + 32 * m + 8 * i;
+                const int ch = sl.row0 + lrow;
+                if (ch < d.cp) {
+                    float bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = a.bias ? a.bias[sl.boff + lrow + 4 * h + q] : 0.0f;
+                    const long long ro = (long long)(ch >> 3) * ld * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (t0 + wn * 128 + 32 * n + r < a.L) {
+                            float v[4];
+                            if (masked) {
+                                float mv[4];
+                                load4<P, BF>(mbase + ro + n * 512, a.z.pstride, mv);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float g = acc[m][n][4 * i + q] * osc;
+                                    v[q] = __builtin_signbitf(mv[q]) ? g * slope : g;      // the SIGN BIT is the mask: +0 = a positive that underflowed
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float y = (acc[m][n][4 * i + q] * osc + bv[q]) * osc2;
+                                    v[q] = y > 0.0f ? y : -__builtin_fabsf(y * slope);     // y <= 0 is stored with the sign bit set (-0 for 0: torch's x > 0 rule)
+                                }
+                            }
+                            store4<P, BF>(dbase + ro + n * 512, d.pstride, v, ovf);
+                        }
+                    }
+                }
+            }
     } else if constexpr (EPI == HEPI_GATE) {
         // tiles (2j, 2j+1) of a wave hold a and g of the same 32 channels
         const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
@@ -850,6 +892,39 @@ __global__ __launch_bounds__(128 * WR, WR == 4 ? 1 : 2) void hgemm8_kernel(const
                 if (nok(n)) store4<P, BF>(prow + n * 256, d.pstride, v, ovf);
             }
         }
+    } else if constexpr (EPI == HEPI_LEAKY) {
+        const HDst d = a.dst[sl.dst];
+        const bool masked = a.z.base != nullptr;
+        const float slope = a.leaky, osc2 = a.oscale2;
+        const long long o0 = col + (long long)(((sl.row0 + wm * 64) >> 3) + (rq >> 1)) * ld * 16;
+        char* dbase = d.base + (long long)b * d.ustride + o0;
+        const char* mbase = masked ? a.z.base + (long long)b * a.z.ustride + o0 : nullptr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const long long ro = (long long)(2 * m) * ld * 16;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (nok(n)) {
+                    float v[4];
+                    if (masked) {
+                        float mv[4];
+                        load4<P, BF>(mbase + ro + n * 256, a.z.pstride, mv);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float g = acc[m][n][q] * osc;
+                            v[q] = __builtin_signbitf(mv[q]) ? g * slope : g;      // the SIGN BIT is the mask: +0 = a positive that underflowed
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float y = (acc[m][n][q] * osc + bvec[m][q]) * osc2;
+                            v[q] = y > 0.0f ? y : -__builtin_fabsf(y * slope);     // y <= 0 is stored with the sign bit set (-0 for 0: torch's x > 0 rule)
+                        }
+                    }
+                    store4<P, BF>(dbase + ro + n * 256, d.pstride, v, ovf);
+                }
+            }
+        }
     } else if constexpr (EPI == HEPI_GATE) {
         // tile rows 0..31 of a wave are a, 32..63 are g of the same 32 channels: pairs (m, m + 2)
         const long long o0 = col + (long long)(((sl.row0 + wm * 32) >> 3) + (rq >> 1)) * ld * 16;
@@ -951,6 +1026,7 @@ static hipError_t launch_h8(int epi, const HGemmArgs& a, unsigned grid, hipStrea
         case HEPI_GATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_GATE, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
         case HEPI_DGATE: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_DGATE, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
         case HEPI_F32: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_F32, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
+        case HEPI_LEAKY: hipLaunchKernelGGL((hgemm8_kernel<P, BF, HEPI_LEAKY, NT, WR>), dim3(grid), dim3(128 * WR), 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -969,9 +1045,10 @@ static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream
         }
     }
     if constexpr (MT == 4) {
-        // 256-row tiles are used by the long-K skips_sum product only (HPlan::init): the other epilogues are not instantiated
-        if (epi != HEPI_F32) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a);
+        // 256-row tiles are used by the long-K skips_sum product only (HPlan::init): dense fp32 out, or the activated half series
+        if (epi == HEPI_F32) hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a);
+        else if (epi == HEPI_LEAKY) hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_LEAKY>), dim3(grid), dim3(256), 0, st, a);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     } else {
         switch (epi) {
@@ -979,6 +1056,7 @@ static hipError_t launch_h(int epi, const HGemmArgs& a, unsigned grid, hipStream
             case HEPI_GATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_GATE>), dim3(grid), dim3(256), 0, st, a); break;
             case HEPI_DGATE: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_DGATE>), dim3(grid), dim3(256), 0, st, a); break;
             case HEPI_F32: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_F32>), dim3(grid), dim3(256), 0, st, a); break;
+            case HEPI_LEAKY: hipLaunchKernelGGL((hgemm_kernel<MT, P, BF, HEPI_LEAKY>), dim3(grid), dim3(256), 0, st, a); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

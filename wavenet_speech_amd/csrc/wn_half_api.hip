@@ -652,6 +652,29 @@ int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* pa
     return WN_OK;
 }
 
+// skips_sum straight into an activated half series (no dense fp32 S): out = leaky(S) * out_scale, the input of the output block's
+// first 1x1 conv (modules/wavenet.py:67-71,103: LeakyReLU, Conv1d, LeakyReLU, Conv1d) when that block stays in the series layout
+int wn_hskipsum_forward_series(const wn_skipsum_shape* s, int precision, const void* packed, const void* const* z, void* out_series,
+                               float out_scale, float leaky_slope, unsigned* overflow_flag, wn_stream_t stream) {
+    int rc = check_hskipsum(s, precision);
+    if (rc != WN_OK) return rc;
+    if (!packed || !z || !out_series) return WN_ERR_NULL;
+    if (!(out_scale > 0.0f)) return WN_ERR_BAD_SHAPE;
+    for (int l = 0; l < s->nblocks; ++l) if (!z[l]) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HPlan g = plan_hskipsum(s, precision);
+    const int P = hp_planes(precision);
+    HGemmArgs a;
+    fill_hgemm(a, g, packed, 0, s->batch, s->length, s->ld, s->halo);
+    double ksum = 0;
+    for (int l = 0; l < s->nblocks; ++l) { set_hseg(a, l, view(z[l], s->channels[l], s->ld, P), 0, g.seg_nks[l]); ksum += s->channels[l]; }
+    a.dst[0] = dst_of(view(out_series, s->skip_rows, s->ld, P));
+    a.oscale2 = out_scale; a.leaky = leaky_slope; a.flag = overflow_flag;
+    wn::ProfScopeShared prof(KC_HSKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_LEAKY, a, st), "hgemm<skipsum series>");
+    return WN_OK;
+}
+
 // ---- every pack job of a stack in one launch -------------------------------------------------------------------------------
 // Training repacks every weight after each optimizer step: five small launches per block plus the long-K skips_sum pack.
 // Their arguments depend only on shapes, precision and pointers, so they are built once into a TABLE that lives on the device
@@ -826,7 +849,7 @@ struct HWPlan {
         const int target = composite ? 256 : 512;
         nsplit = std::max(1, target / std::max(1, ntile_total));
         nsplit = std::min(nsplit, std::max(1, nstep / 8));      // at least a few k-steps per split
-        if (nsplit >= 16) nsplit = nsplit / 8 * 8;
+        if (nsplit >= 16 && !(composite && ntile_total > 3)) nsplit = nsplit / 8 * 8;   // (XCD-aware placement needs a multiple of 8)
     }
     bool xcd_map() const { return nsplit % 8 == 0; }
     size_t bytes() const { return (size_t)nsplit * (size_t)(slab_floats + rs_floats) * 4; }
@@ -894,7 +917,7 @@ int run_hwgrad(const std::vector<HPairSpec>& ps, int prec, int B, int L, int ld,
         else wp.add(p.a[0].rows, p.b[0].rows);
         ndst += (int)p.q.size();
     }
-    if (wp.npair > kMaxPair || ndst > kMaxPair) return WN_ERR_UNSUPPORTED;
+    if (wp.npair > kMaxPair || ndst > kMaxReduceDst) return WN_ERR_UNSUPPORTED;
     const int spr = cdiv(L, 32);                      // stages of 32 time steps per utterance (hwgrad_kernel)
     wp.finish(B * spr);
     if (need) *need = wp.bytes();
@@ -981,6 +1004,68 @@ int wn_hblock_backward_weights(const wn_block_shape* s, int precision, const voi
     std::vector<HPairSpec> ps = hblock_pairs(s, off, x, z, da, dg, dr, dskip, grads);
     return run_hwgrad(ps, precision, s->batch, s->length, s->ld, s->halo, dyn_inv_scale, workspace, workspace_bytes, false,
                       nullptr, (hipStream_t)stream);
+}
+
+// ---- the weight gradients of SEVERAL blocks in one launch -----------------------------------------------------------------------
+// Small blocks (<= 128 channels: composite pairs, two or three 256 x 256 tiles per block) leave a split-K launch per block with
+// 128 splits of 32 stages each and 67 MB of partial slabs that the reduction re-reads -- per block.  Their operands (x, z, da,
+// dg, dr, dskip) can simply be kept until several blocks have run backward_data: one launch then holds all their tiles, the
+// split count falls to ~256 / tiles (long K loops), and the partial slabs of the whole group are what ONE block wrote before.
+namespace {
+constexpr int kMaxGroupBlocks = 8;     // 2 pairs and <= 7 destinations per block: kMaxPair / kMaxReduceDst
+}
+
+int wn_hblocks_wgrad_group_max(const wn_block_shape* s, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hblock(s, precision, off) != WN_OK) return 0;
+    if (!composite_wgrad(s->in_channels, s->out_channels, s->skip_rows)) return 1;
+    const int pairs = (s->kernel_width + 1) / 2 + 1, dsts = 2 * s->kernel_width + 3;
+    return std::max(1, std::min(kMaxGroupBlocks, std::min(kMaxPair / pairs, kMaxReduceDst / dsts)));
+}
+
+size_t wn_hblocks_wgrad_workspace_bytes(const wn_block_shape* shapes, int nblocks, int precision) {
+    if (!shapes || nblocks <= 0) return 0;
+    static const float dummy = 0;
+    std::vector<HPairSpec> all;
+    for (int l = 0; l < nblocks; ++l) {
+        int off[WN_MAX_TAPS];
+        if (check_hblock(&shapes[l], precision, off) != WN_OK) return 0;
+        if (shapes[l].batch != shapes[0].batch || shapes[l].length != shapes[0].length || shapes[l].ld != shapes[0].ld ||
+            shapes[l].halo != shapes[0].halo)
+            return 0;
+        std::vector<HPairSpec> ps = hblock_pairs(&shapes[l], off, &dummy, &dummy, &dummy, &dummy, &dummy, &dummy, nullptr);
+        all.insert(all.end(), ps.begin(), ps.end());
+    }
+    size_t need = 0;
+    if (run_hwgrad(all, precision, shapes[0].batch, shapes[0].length, shapes[0].ld, shapes[0].halo, nullptr, nullptr, 0, true, &need,
+                   nullptr) != WN_OK)
+        return 0;
+    return need;
+}
+
+int wn_hblocks_backward_weights(const wn_block_shape* shapes, int nblocks, int precision, const void* const* x, const void* const* z,
+                                const void* const* da, const void* const* dg, const void* const* dr, const void* const* dskip,
+                                const wn_block_params* grads, const float* dyn_inv_scale, void* workspace, size_t workspace_bytes,
+                                wn_stream_t stream) {
+    if (!shapes || !x || !z || !da || !dg || !dr || !dskip || !grads) return WN_ERR_NULL;
+    if (nblocks <= 0) return WN_ERR_BAD_SHAPE;
+    std::vector<HPairSpec> all;
+    for (int l = 0; l < nblocks; ++l) {
+        int off[WN_MAX_TAPS];
+        int rc = check_hblock(&shapes[l], precision, off);
+        if (rc != WN_OK) return rc;
+        if (shapes[l].batch != shapes[0].batch || shapes[l].length != shapes[0].length || shapes[l].ld != shapes[0].ld ||
+            shapes[l].halo != shapes[0].halo)
+            return WN_ERR_BAD_SHAPE;                            // one series geometry per launch
+        const wn_block_params* g = &grads[l];
+        if (!x[l] || !z[l] || !da[l] || !dg[l] || !dskip[l]) return WN_ERR_NULL;
+        if (!g->w_tanh || !g->b_tanh || !g->w_sigmoid || !g->b_sigmoid || !g->w_skip || !g->b_skip) return WN_ERR_NULL;
+        if (dr[l] && (!g->w_res || !g->b_res || !g->w_proj || !g->b_proj)) return WN_ERR_NULL;
+        std::vector<HPairSpec> ps = hblock_pairs(&shapes[l], off, x[l], z[l], da[l], dg[l], dr[l], dskip[l], g);
+        all.insert(all.end(), ps.begin(), ps.end());
+    }
+    return run_hwgrad(all, precision, shapes[0].batch, shapes[0].length, shapes[0].ld, shapes[0].halo, dyn_inv_scale, workspace,
+                      workspace_bytes, false, nullptr, (hipStream_t)stream);
 }
 
 // ==========================================================================================================================
@@ -1088,6 +1173,54 @@ int wn_hconv_backward_data(const wn_conv_shape* s, int precision, const void* pa
     a.out32 = dx_dense; a.out32_rows = Ci; a.out32_accum = 0; a.dyn_inv = dyn_inv_scale;
     wn::ProfScopeShared prof(KC_HCONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
     WN_HIP(launch_hgemm(precision, cp.kb.kernel(), HEPI_F32, a, st), "hgemm<conv dx>");
+    return WN_OK;
+}
+
+// The same convolution with the half series on BOTH sides (the feature layer / output block of a model in a half mode stay in the
+// layout between their convs): y_series = leaky(conv(x) + b) * out_scale  (leaky_slope = 1: no activation).  `packed` from
+// wn_hconv_pack with the input's scale.
+int wn_hconv_forward_series(const wn_conv_shape* s, int precision, const void* packed, const void* x, void* y_series, float out_scale,
+                            float leaky_slope, unsigned* overflow_flag, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !x || !y_series) return WN_ERR_NULL;
+    if (!(out_scale > 0.0f)) return WN_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const HConvPlan cp = plan_hconv(s, precision);
+    const int P = hp_planes(precision), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    HGemmArgs a;
+    fill_hgemm(a, cp.f, packed, cp.off_f, s->batch, s->length, s->ld, s->halo);
+    const HView vx = view(x, Ci, s->ld, P);
+    for (int j = 0; j < k; ++j) set_hseg(a, j, vx, off[j], cp.f.seg_nks[j]);
+    a.dst[0] = dst_of(view(y_series, Co, s->ld, P));
+    a.oscale2 = out_scale; a.leaky = leaky_slope; a.flag = overflow_flag;
+    wn::ProfScopeShared prof(KC_HCONV_FWD, 2.0 * Co * (double)(k * Ci) * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, cp.f.kernel(), HEPI_LEAKY, a, st), "hgemm<conv series>");
+    return WN_OK;
+}
+
+// dx_series = (W^T dy) * leaky'(act): `act` (nullable: no activation in front of this conv) is the conv's INPUT as it was stored,
+// i.e. the activated value, whose sign is the sign of the pre-activation; gradients keep the scale dy carries
+int wn_hconv_backward_data_series(const wn_conv_shape* s, int precision, const void* packed, const void* dy, const void* act,
+                                  float leaky_slope, void* dx_series, unsigned* overflow_flag, wn_stream_t stream) {
+    int off[WN_MAX_TAPS];
+    int rc = check_hconv(s, precision, off);
+    if (rc != WN_OK) return rc;
+    if (!packed || !dy || !dx_series) return WN_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const HConvPlan cp = plan_hconv(s, precision);
+    const int P = hp_planes(precision), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    HGemmArgs a;
+    fill_hgemm(a, cp.kb, packed, cp.off_kb, s->batch, s->length, s->ld, s->halo);
+    a.bias = nullptr;
+    const HView vdy = view(dy, Co, s->ld, P);
+    for (int j = 0; j < k; ++j) set_hseg(a, j, vdy, -off[j], cp.kb.seg_nks[j]);
+    a.dst[0] = dst_of(view(dx_series, Ci, s->ld, P));
+    if (act) a.z = dst_of(view(act, Ci, s->ld, P));
+    a.oscale2 = 1.0f; a.leaky = act ? leaky_slope : 1.0f; a.flag = overflow_flag;
+    wn::ProfScopeShared prof(KC_HCONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
+    WN_HIP(launch_hgemm(precision, cp.kb.kernel(), HEPI_LEAKY, a, st), "hgemm<conv dx series>");
     return WN_OK;
 }
 

@@ -102,6 +102,7 @@ struct PackArgs {
 // weight-gradient kernel: out_p[M x N] = sum_{b,t} A_p[b][m][t] * B_p[b][n][t + off_p]
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxPair = 2 * 8 + 3;  // 2*WN_MAX_TAPS + 3
+constexpr int kMaxReduceDst = 56;    // destinations of one reduction launch (a composite pair of the half path has up to four; several blocks per launch)
 struct WgradPair {
     const float* A; const float* Bm;
     int a_cp, b_cp;       // rows per batch element
@@ -136,13 +137,15 @@ struct ReduceDst {
     int rs_off;
     float post;           // the matrix is multiplied by this on the way out (1 in the fp32 path; 1/input scale in the half path)
 };
-struct ReduceArgs {
-    ReduceDst d[kMaxPair];
+struct ReduceArgs {   // <= 4 KiB: it travels as a kernel argument
+    ReduceDst d[kMaxReduceDst];
     int npair, nsplit;
     const float* slab; const float* rowsum;
     long long slab_floats; int rs_floats;
     const float* dyn_inv; // optional device scalar multiplied into every output (1 / dynamic gradient scale of the half path)
 };
+
+static_assert(sizeof(ReduceArgs) <= 4096 && sizeof(WgradArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 // launchers (defined in the .hip files)
 hipError_t launch_gemm(int MT, int epi, const GemmArgs& a, hipStream_t st);

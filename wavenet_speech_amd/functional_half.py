@@ -153,11 +153,18 @@ class _HalfStackFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, *flat):
+    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, head, *flat):
+        """head: None, or (slope1, slope2) of an output block LeakyReLU(slope1), Conv1d 1x1, LeakyReLU(slope2), Conv1d 1x1
+        (modules/wavenet.py:67-71, raw_ctcnet.py:89-93) whose parameters (w1, b1, w2, b2) are the last four tensors of `flat`:
+        the block then runs inside this function, in the half series, and the function returns its output instead of skips_sum."""
         lib = _lib.load()
         _require_device(x, "input")
         _flags.WATCH.poll()
         n = len(specs)
+        head_params = None
+        if head is not None:
+            head_params = [t.detach().contiguous() for t in flat[-4:]]
+            flat = flat[:-4]
         assert len(flat) == n * PARAMS_PER_BLOCK
         B, C0, L = x.shape
         if C0 != specs[0].ci:
@@ -237,6 +244,8 @@ class _HalfStackFn(torch.autograd.Function):
                 skip_w.append(params[6])
                 skip_b.append(params[7])
             cur = r
+        series_head = head is not None and training and n <= _lib.MAX_STACK_GROUP
+        ctx.skipsum_packed = None
         if training:
             G = _lib.MAX_STACK_GROUP
             bias_total = torch.stack(skip_b).sum(0).contiguous() if table is None else None
@@ -257,9 +266,51 @@ class _HalfStackFn(torch.autograd.Function):
                     wptrs = (ctypes.c_void_p * m)(*[skip_w[l].data_ptr() for l in idx])
                     _lib.check(lib.wn_hskipsum_pack(ctypes.byref(shape), mode.code, wptrs, _p(bias_total) if g0 == 0 else None,
                                                     _p(packed), _stream()), "wn_hskipsum_pack")
-                _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
-                                                   0 if g0 == 0 else 1, _stream()), "wn_hskipsum_forward")
+                if series_head:
+                    ctx.skipsum_packed = packed            # the head below writes leaky(S) as a series: no dense S
+                else:
+                    _lib.check(lib.wn_hskipsum_forward(ctypes.byref(shape), mode.code, _p(packed), zptrs, _p(S),
+                                                       0 if g0 == 0 else 1, _stream()), "wn_hskipsum_forward")
         ctx.packed_all = packed_all       # the blocks' packed weights live here until backward has run
+        ctx.head = None
+        if head is not None:
+            # ---- output block in the series layout: leaky(S) -> conv1 -> leaky -> conv2 (dense fp32 out) ------------------------
+            w1, b1, w2, b2 = head_params
+            c1, c2 = w1.shape[0], w2.shape[0]
+            if w1.shape[1] != ms or w2.shape[1] != c1 or w1.shape[2] != 1 or w2.shape[2] != 1:
+                raise RuntimeError("wavenet_speech_amd: output block shapes %s, %s do not follow a stack of out_dim %d"
+                                   % (tuple(w1.shape), tuple(w2.shape), ms))
+            sh1 = _lib.ConvShape(B, L, ms, c1, 1, 1, 1, layout.ld, layout.halo)
+            sh2 = _lib.ConvShape(B, L, c1, c2, 1, 1, 1, layout.ld, layout.halo)
+            pk = []
+            for sh, w, b_ in ((sh1, w1, b1), (sh2, w2, b2)):
+                nbytes = lib.wn_hconv_packed_bytes(ctypes.byref(sh), mode.code)
+                if nbytes == 0:
+                    _lib.check(-1, "wn_hconv_packed_bytes")
+                p_ = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _lib.check(lib.wn_hconv_pack(ctypes.byref(sh), mode.code, _p(w), _p(b_), ctypes.c_float(rs), _p(p_), _stream()),
+                           "wn_hconv_pack")
+                pk.append(p_)
+            h0 = _hlease(mode, B, ms, layout, dev)
+            if series_head:
+                # the long-K skips_sum product writes leaky(S) / 16 straight into the series: no dense fp32 S at all
+                skshape = _lib.SkipSumShape(B, L, ms, n, layout.ld, layout.halo)
+                for i in range(n):
+                    skshape.channels[i] = specs[i].co
+                zptrs = (ctypes.c_void_p * n)(*[saved[l][2].ptr for l in range(n)])
+                _lib.check(lib.wn_hskipsum_forward_series(ctypes.byref(skshape), mode.code, _p(ctx.skipsum_packed), zptrs, _p(h0),
+                                                          ctypes.c_float(rs), ctypes.c_float(head[0]), _p(flag), _stream()),
+                           "wn_hskipsum_forward_series")
+            else:
+                _load(lib, mode, torch.nn.functional.leaky_relu(S, head[0]), h0, layout, rs, None, flag)
+            h1 = _hlease(mode, B, c1, layout, dev)
+            _lib.check(lib.wn_hconv_forward_series(ctypes.byref(sh1), mode.code, _p(pk[0]), _p(h0), _p(h1), ctypes.c_float(rs),
+                                                   ctypes.c_float(head[1]), _p(flag), _stream()), "wn_hconv_forward_series")
+            y = torch.empty(B, c2, L, dtype=torch.float32, device=dev)
+            _lib.check(lib.wn_hconv_forward(ctypes.byref(sh2), mode.code, _p(pk[1]), _p(h1), _p(y), _stream()), "wn_hconv_forward")
+            if training:
+                ctx.head = (head, sh1, sh2, pk, h0, h1, [tuple(t.shape) for t in head_params])
+            S = y
         _flags.WATCH.note(flag, _OVERFLOW_MSG % "forward pass", at_once=not training)
         ctx.specs, ctx.saved, ctx.layout, ctx.batch, ctx.mode = specs, saved, layout, B, mode
         ctx.param_shapes = [tuple(t.shape) for t in flat]
@@ -276,11 +327,59 @@ class _HalfStackFn(torch.autograd.Function):
         d_skips = d_skips.contiguous()
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
         dyn, dyn_inv = _grad_scale(d_skips, mode)
-        dS = _hlease(mode, B, specs[0].ms, layout, dev)
-        _load(lib, mode, d_skips, dS, layout, 1.0, dyn, flag)
+        head_grads = []
+        if ctx.head is None:
+            dS = _hlease(mode, B, specs[0].ms, layout, dev)
+            _load(lib, mode, d_skips, dS, layout, 1.0, dyn, flag)
+        else:
+            # ---- output block, backwards, in the series: d_skips is the cotangent of its OUTPUT here ----------------------------
+            (slope1, slope2), sh1, sh2, pk, h0, h1, hshapes = ctx.head
+            rs = float(lib.wn_hseries_residual_scale())
+            c1, c2 = sh1.out_channels, sh2.out_channels
+            dY = _hlease(mode, B, c2, layout, dev)
+            _load(lib, mode, d_skips, dY, layout, 1.0, dyn, flag)
+            dh1 = _hlease(mode, B, c1, layout, dev)
+            _lib.check(lib.wn_hconv_backward_data_series(ctypes.byref(sh2), mode.code, _p(pk[1]), _p(dY), _p(h1), ctypes.c_float(slope2),
+                                                         _p(dh1), _p(flag), _stream()), "wn_hconv_backward_data_series")
+            dS = _hlease(mode, B, specs[0].ms, layout, dev)
+            _lib.check(lib.wn_hconv_backward_data_series(ctypes.byref(sh1), mode.code, _p(pk[0]), _p(dh1), _p(h0), ctypes.c_float(slope1),
+                                                         _p(dS), _p(flag), _stream()), "wn_hconv_backward_data_series")
+            for sh, xin, dy_, shp_w, shp_b in ((sh1, h0, dh1, hshapes[0], hshapes[1]), (sh2, h1, dY, hshapes[2], hshapes[3])):
+                dw = torch.empty(shp_w, dtype=torch.float32, device=dev)
+                db = torch.empty(shp_b, dtype=torch.float32, device=dev)
+                ws_bytes = lib.wn_hconv_wgrad_workspace_bytes(ctypes.byref(sh), mode.code)
+                ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+                _lib.check(lib.wn_hconv_backward_weights(ctypes.byref(sh), mode.code, _p(xin), _p(dy_), ctypes.c_float(rs), _p(dw), _p(db),
+                                                         _p(dyn_inv), _p(ws), ws_bytes, _stream()), "wn_hconv_backward_weights")
+                head_grads += [dw, db]
+            ctx.head = None
         dr = None
         dx0 = None
         grads_flat = [None] * (len(specs) * PARAMS_PER_BLOCK)
+        # weight gradients: small blocks (<= 128 channels) are two or three gradient tiles each -- their operands are kept and
+        # several blocks go into ONE split-K launch + ONE reduction (wn_hblocks_backward_weights); WN_WGRAD_GROUP=1 = per block
+        group_max = lib.wn_hblocks_wgrad_group_max(ctypes.byref(ctx.saved[0][4]), mode.code)
+        env_group = os.environ.get("WN_WGRAD_GROUP")
+        if env_group:
+            group_max = max(1, min(group_max, int(env_group)))
+        pending = []          # (l, shape, x, z, da, dg, dr, grads) of blocks whose weight gradients are not launched yet
+
+        def flush():
+            if not pending:
+                return
+            m = len(pending)
+            shapes = (_lib.BlockShape * m)(*[e[1] for e in pending])
+            arr = lambda i: (ctypes.c_void_p * m)(*[(e[i].ptr if e[i] is not None else None) for e in pending])
+            dsk = (ctypes.c_void_p * m)(*[dS.ptr] * m)
+            gs = (_lib.BlockParams * m)(*[_params_struct(e[7]) for e in pending])
+            ws_bytes = lib.wn_hblocks_wgrad_workspace_bytes(shapes, m, mode.code)
+            if ws_bytes == 0:
+                _lib.check(-1, "wn_hblocks_wgrad_workspace_bytes")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.wn_hblocks_backward_weights(shapes, m, mode.code, arr(2), arr(3), arr(4), arr(5), arr(6), dsk, gs,
+                                                       _p(dyn_inv), _p(ws), ws_bytes, _stream()), "wn_hblocks_backward_weights")
+            del pending[:]
+
         for l in range(len(specs) - 1, -1, -1):
             spec = specs[l]
             x, sg, z, packed, shape = ctx.saved[l]
@@ -298,24 +397,36 @@ class _HalfStackFn(torch.autograd.Function):
                       (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]
             unused = (4, 5, 8, 9) if dr is None else ()
             grads = [None if i in unused else torch.empty(s, dtype=torch.float32, device=dev) for i, s in enumerate(shapes)]
-            ws_bytes = lib.wn_hblock_wgrad_workspace_bytes(ctypes.byref(shape), mode.code)
-            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-            gs = _params_struct(grads)
-            _lib.check(lib.wn_hblock_backward_weights(ctypes.byref(shape), mode.code, _p(x), _p(z), _p(da), _p(dg), _p(dr),
-                                                      _p(dS), ctypes.byref(gs), _p(dyn_inv), _p(ws), ws_bytes, _stream()),
-                       "wn_hblock_backward_weights")
+            if group_max > 1:
+                pending.append((l, shape, x, z, da, dg, dr, grads))
+                if len(pending) >= group_max:
+                    flush()
+            else:
+                ws_bytes = lib.wn_hblock_wgrad_workspace_bytes(ctypes.byref(shape), mode.code)
+                ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+                gs = _params_struct(grads)
+                _lib.check(lib.wn_hblock_backward_weights(ctypes.byref(shape), mode.code, _p(x), _p(z), _p(da), _p(dg), _p(dr),
+                                                          _p(dS), ctypes.byref(gs), _p(dyn_inv), _p(ws), ws_bytes, _stream()),
+                           "wn_hblock_backward_weights")
             grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
             dr = dx
             ctx.saved[l] = None
+        flush()
         _flags.WATCH.note(flag, _OVERFLOW_MSG % "backward pass", at_once=False)
         grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
-        return (dx0, None, None, None, None) + tuple(grads_flat)
+        return (dx0, None, None, None, None, None) + tuple(grads_flat) + tuple(head_grads)
 
 
-def residual_stack(x, specs, flat_params, precision, pack_cache=None):
+def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None):
+    """head: None, or ((slope1, slope2), [w1, b1, w2, b2]) of an output block LeakyReLU, Conv1d 1x1, LeakyReLU, Conv1d 1x1 that is
+    to run inside the same function, in the half series: the result is then that block's output, not skips_sum."""
     if precision not in ("f16x3", "f16", "bf16"):
         raise ValueError("unknown precision %r" % (precision,))
-    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, *flat_params)
+    if head is None:
+        return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, None, *flat_params)
+    slopes, hp = head
+    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache,
+                              (float(slopes[0]), float(slopes[1])), *(list(flat_params) + list(hp)))
 
 
 class _HalfConvFn(torch.autograd.Function):

@@ -168,8 +168,30 @@ def freeze_for_inference(module, on=True):
     return module
 
 
-def run_stack(out, blocks, bottlenecks, state=None):
-    """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path"""
+def fusable_head(head, precision):
+    """(slopes, parameters) of an output block that can run inside the half-precision stack function, in the series layout:
+    exactly LeakyReLU, Conv1d 1x1, LeakyReLU, Conv1d 1x1 (every reference model's output_stack / output_block), in a half mode
+    whose head convs follow the stack (head_precision).  None otherwise: the caller then evaluates the block itself."""
+    import os
+    import torch.nn as nn
+    if head is None or os.environ.get("WN_SERIES_HEAD", "1") == "0":
+        return None
+    if precision == "f32" or head_precision(precision) != precision:
+        return None
+    mods = list(head)
+    if len(mods) != 4 or not (isinstance(mods[0], nn.LeakyReLU) and isinstance(mods[2], nn.LeakyReLU)):
+        return None
+    for c in (mods[1], mods[3]):
+        if not isinstance(c, nn.Conv1d) or c.kernel_size != (1,) or c.stride != (1,) or c.padding != (0,) or c.groups != 1 \
+                or c.bias is None:
+            return None
+    return (mods[0].negative_slope, mods[2].negative_slope), [mods[1].weight, mods[1].bias, mods[3].weight, mods[3].bias]
+
+
+def run_stack(out, blocks, bottlenecks, state=None, head=None):
+    """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path.
+    With `head` (the model's output block) returns (tensor, head_done): in the half modes the output block runs inside the same
+    function, in the series layout (no dense fp32 skips_sum, no separate LeakyReLU passes), and `tensor` is its output."""
     specs, flat = [], []
     out_dim = bottlenecks[0].out_channels
     blocks, bottlenecks = list(blocks), list(bottlenecks)
@@ -191,4 +213,6 @@ def run_stack(out, blocks, bottlenecks, state=None):
     for blk, w, b in zip(blocks, wfs, bfs):
         specs.append(blk.spec(out_dim))
         flat.extend(blk.hip_params(w, b))
-    return HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache)
+    fh = fusable_head(head, precision)
+    res = HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache, head=fh)
+    return res if head is None else (res, fh is not None)

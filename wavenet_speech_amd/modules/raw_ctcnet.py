@@ -61,8 +61,9 @@ class RawCTCNet(nn.Module):
             steps = torch.arange(0., out.size(2), device=seq.device).view(1, 1, -1)
             out = out + run_sequential(self.positions_conv1x1, steps, pointwise_precision(self.stack_state.precision))
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
-                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state)
-        logit_seq = run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
+                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state, head=self.output_block)
+        skips_sum, done = skips_sum
+        logit_seq = skips_sum if done else run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
             return logit_seq
         return F.softmax(logit_seq, dim=1)

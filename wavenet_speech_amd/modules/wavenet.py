@@ -58,8 +58,8 @@ class WaveNet(nn.Module):
         return self._after_entry(out)
 
     def _after_entry(self, out):
-        skips_sum = run_stack(out, self.convolutions, self.bottlenecks, self.stack_state)
-        output_seq = run_sequential(self.output_stack, skips_sum, head_precision(self.stack_state.precision))
+        skips_sum, done = run_stack(out, self.convolutions, self.bottlenecks, self.stack_state, head=self.output_stack)
+        output_seq = skips_sum if done else run_sequential(self.output_stack, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
             return output_seq
         return F.softmax(output_seq, dim=1)  # the reference's reshape_in/softmax/reshape_out == softmax over channels
