@@ -308,6 +308,35 @@ int wn_hconv_forward_series(const wn_conv_shape* s, int precision, const void* p
 int wn_hconv_backward_data_series(const wn_conv_shape* s, int precision, const void* packed, const void* dy, const void* act,
                                   float leaky_slope, void* dx_series, unsigned* overflow_flag, wn_stream_t stream);
 
+/* The first block of a stack whose input x is the ACTIVATED output of a front-end conv kept in the series (x_act = leaky(.) as
+ * stored): dx = (input gradient) * leaky'(x_act), written to the half series dx -- wn_hblock_backward_data plus the LeakyReLU
+ * backward of the layer in front, in one epilogue. */
+int wn_hblock_backward_data_masked(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                                   const void* z, const void* sg, void* da, void* dg, void* dx, const void* x_act, float leaky_slope,
+                                   unsigned* overflow_flag, wn_stream_t stream);
+
+/* Front-ends that are not GEMM-shaped, written straight into the stack's layouts (csrc/wn_front.hip):
+ *   wn_hfeature_forward            RawCTCNet.feature_layer[0..1] (reference modules/raw_ctcnet.py:57-61,128): Conv1d(1 -> F, k,
+ *                                  padding k - 1) + LeakyReLU of the raw signal x [B][length] -> half series of length length + k - 1,
+ *                                  stored * out_scale (k multiply-adds per element: elementwise work, not a GEMM with 31/32 of K zero)
+ *   wn_hfeature_backward_weights   dW [F][1][k], db [F] from the series gradient of that layer's output (* dyn_inv_scale / dy_scale);
+ *                                  deterministic (per-slab partial sums reduced in slab order)
+ *   wn_hseries_load_pooled /       WaveNetClassifier.mean_pool (reference modules/classifier.py:53,102): AvgPool1d(pool) fused into
+ *   wn_series_load_pooled          the load of the stack's input (half series / fp32 padded series of length length / pool)
+ *   wn_pool_backward               dx[b][c][t] = dpooled[b][c][t / pool] / pool (0 for a dropped tail), both dense fp32 */
+int wn_hfeature_forward(int precision, const float* x, const float* weight, const float* bias, void* y_series, int batch, int length,
+                        int features, int kernel_width, int ld, int halo, float out_scale, float leaky_slope, unsigned* overflow_flag,
+                        wn_stream_t stream);
+size_t wn_hfeature_wgrad_workspace_bytes(int batch, int length, int features, int kernel_width);
+int wn_hfeature_backward_weights(int precision, const float* x, const void* dy_series, float dy_scale, float* dweight, float* dbias,
+                                 int batch, int length, int features, int kernel_width, int ld, int halo, const float* dyn_inv_scale,
+                                 void* workspace, size_t workspace_bytes, wn_stream_t stream);
+int wn_hseries_load_pooled(int precision, const float* dense, void* series, int batch, int channels, int length, int pool, int ld, int halo,
+                           float scale, const float* dyn_scale, unsigned* overflow_flag, wn_stream_t stream);
+int wn_series_load_pooled(const float* dense, float* series, int batch, int channels, int length, int pool, int ld, int halo,
+                          wn_stream_t stream);
+int wn_pool_backward(const float* dpooled, float* dx, int batch, int channels, int length, int pool, wn_stream_t stream);
+
 /* The weight gradients of SEVERAL blocks of one series geometry in one launch (+ one reduction): blocks of <= 128 channels are
  * two or three gradient tiles each, so per-block launches are short split-K jobs dominated by their partial slabs; keep the
  * operands of up to wn_hblocks_wgrad_group_max() blocks (after their wn_hblock_backward_data calls) and hand them over

@@ -275,10 +275,10 @@ def capture_leaky_slopes(model):
     """Register forward-pre-hooks on every nn.LeakyReLU of `model`; returns (slopes dict, remove()).  After a forward
     pass slopes["<module name>"] holds the per-element slope (1 where the input was > 0, else 0.01) on the CPU.
 
-    In the half-precision modes the HIP package runs the output block INSIDE its stack function (series layout): the
-    LeakyReLU modules are then never called.  Its un-fused form is bitwise the same forward computation
-    (tests/test_gpu_head.py), so the pattern is taken from one extra no_grad forward in that form (WN_SERIES_HEAD=0),
-    run by a hook on the model itself just before the real, fused forward."""
+    In the half-precision modes the HIP package runs the output block (and RawCTCNet's feature layer) INSIDE its stack
+    function (series layout): the LeakyReLU modules are then never called.  The un-fused form is the same forward computation
+    (tests/test_gpu_head.py: bitwise for the output block), so the pattern is taken from one extra no_grad forward in that form
+    (WN_SERIES_HEAD=0, WN_SERIES_FRONT=0), run by a hook on the model itself just before the real, fused forward."""
     import os
     import torch.nn as nn
     slopes, handles = {}, []
@@ -294,16 +294,18 @@ def capture_leaky_slopes(model):
         if state["busy"]:
             return
         state["busy"] = True
-        old = os.environ.get("WN_SERIES_HEAD")
-        os.environ["WN_SERIES_HEAD"] = "0"
+        old = {k: os.environ.get(k) for k in ("WN_SERIES_HEAD", "WN_SERIES_FRONT")}
+        for k in old:
+            os.environ[k] = "0"
         try:
             with torch.no_grad():
                 m(*[t.detach() if isinstance(t, torch.Tensor) else t for t in inp])
         finally:
-            if old is None:
-                os.environ.pop("WN_SERIES_HEAD", None)
-            else:
-                os.environ["WN_SERIES_HEAD"] = old
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             state["busy"] = False
     if any(getattr(m, "stack_state", None) is not None for m in model.modules()):
         handles.append(model.register_forward_pre_hook(unfused_first))

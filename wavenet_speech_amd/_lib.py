@@ -94,6 +94,17 @@ SIGNATURES = {
     "wn_hskipsum_forward": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_float_p, c_int, c_void_p]),
     "wn_hblock_backward_data": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_float_p, c_float_p, c_void_p, c_void_p]),
+    "wn_hblock_backward_data_masked": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "wn_hfeature_forward": (c_int, [c_int, c_float_p, c_float_p, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    c_float, c_void_p, c_void_p]),
+    "wn_hfeature_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wn_hfeature_backward_weights": (c_int, [c_int, c_float_p, c_void_p, c_float, c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int,
+                                             c_int, c_float_p, c_void_p, c_size_t, c_void_p]),
+    "wn_hseries_load_pooled": (c_int, [c_int, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float_p, c_void_p,
+                                       c_void_p]),
+    "wn_series_load_pooled": (c_int, [c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wn_pool_backward": (c_int, [c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wn_hskipsum_forward_series": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_void_p, c_float, c_float, c_void_p,
                                            c_void_p]),
     "wn_hconv_forward_series": (c_int, [POINTER(ConvShape), c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p]),

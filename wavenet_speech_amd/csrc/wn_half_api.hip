@@ -536,9 +536,11 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
     return WN_OK;
 }
 
-int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
-                            const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
-                            const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream) {
+namespace {
+int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                              const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                              const float* dyn_inv_scale, const void* dx_mask, float dx_slope, unsigned* overflow_flag,
+                              wn_stream_t stream) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
@@ -576,7 +578,13 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
         for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = 2 * k + (dr ? 1 : 0);
         a.flag = overflow_flag;
         wn::ProfScopeShared prof(KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
-        if (dx) {
+        if (dx && dx_mask) {
+            // the block's input was leaky(.) of a front-end conv kept in the series: dx is masked by its stored activation
+            a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
+            a.z = dst_of(view(dx_mask, Ci, s->ld, P));
+            a.oscale2 = 1.0f; a.leaky = dx_slope;
+            WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_LEAKY, a, st), "hgemm<dx masked>");
+        } else if (dx) {
             a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
             WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_STORE, a, st), "hgemm<dx>");
         } else {
@@ -585,6 +593,22 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
         }
     }
     return WN_OK;
+}
+}  // namespace
+
+int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                            const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
+                            const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream) {
+    return hblock_backward_data_impl(s, precision, packed, dr, dskip, z, sg, da, dg, dx, dx_dense, dyn_inv_scale, nullptr, 1.0f,
+                                     overflow_flag, stream);
+}
+
+int wn_hblock_backward_data_masked(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
+                                   const void* z, const void* sg, void* da, void* dg, void* dx, const void* x_act, float leaky_slope,
+                                   unsigned* overflow_flag, wn_stream_t stream) {
+    if (!dx || !x_act) return WN_ERR_NULL;
+    return hblock_backward_data_impl(s, precision, packed, dr, dskip, z, sg, da, dg, dx, nullptr, nullptr, x_act, leaky_slope,
+                                     overflow_flag, stream);
 }
 
 // ---- skips_sum of a whole stack ----------------------------------------------------------------------------------------

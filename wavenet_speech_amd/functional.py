@@ -281,15 +281,15 @@ class PackCache(object):
         return t
 
 
-def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None, head=None):
+def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None, head=None, front=None):
     """skips_sum of a stack of residual blocks.  flat_params: 10 tensors per block in C-ABI order
     (w_tanh, b_tanh, w_sigmoid, b_sigmoid, w_res [Co,Co,1], b_res, w_skip [Ms,Co], b_skip, w_proj, b_proj).
     precision: "f32" (exact fp32 MFMA, default) or one of the half-precision MFMA modes of functional_half."""
     if precision != "f32":
         from . import functional_half
-        return functional_half.residual_stack(x, specs, flat_params, precision, pack_cache, head)
-    if head is not None:
-        raise ValueError("the fused output block exists in the half-precision modes only")
+        return functional_half.residual_stack(x, specs, flat_params, precision, pack_cache, head, front)
+    if head is not None or front is not None:
+        raise ValueError("the fused output block / feature layer exist in the half-precision modes only")
     return _ResidualStackFn.apply(x, tuple(specs), torch.is_grad_enabled(), pack_cache, *flat_params)
 
 

@@ -153,7 +153,7 @@ class _HalfStackFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, head, *flat):
+    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, head, front, *flat):
         """head: None, or (slope1, slope2) of an output block LeakyReLU(slope1), Conv1d 1x1, LeakyReLU(slope2), Conv1d 1x1
         (modules/wavenet.py:67-71, raw_ctcnet.py:89-93) whose parameters (w1, b1, w2, b2) are the last four tensors of `flat`:
         the block then runs inside this function, in the half series, and the function returns its output instead of skips_sum."""
@@ -161,12 +161,22 @@ class _HalfStackFn(torch.autograd.Function):
         _require_device(x, "input")
         _flags.WATCH.poll()
         n = len(specs)
-        head_params = None
-        if head is not None:
+        head_params = front_params = None
+        if front is not None:      # (slope0, slope1): RawCTCNet.feature_layer = Conv1d(1 -> F, k, padding k - 1), LeakyReLU, Conv1d 1x1, LeakyReLU
+            front_params = [t.detach().contiguous() for t in flat[-4:]]   # parameters w0, b0, w1, b1: the LAST four tensors of flat
+            flat = flat[:-4]
+        if head is not None:       # its parameters (w1, b1, w2, b2) come right before the front's
             head_params = [t.detach().contiguous() for t in flat[-4:]]
             flat = flat[:-4]
         assert len(flat) == n * PARAMS_PER_BLOCK
         B, C0, L = x.shape
+        if front is not None:
+            fw0, fb0, fw1, fb1 = front_params
+            if C0 != 1 or fw0.shape[1] != 1 or fw1.shape[2] != 1 or fw1.shape[1] != fw0.shape[0]:
+                raise RuntimeError("wavenet_speech_amd: feature layer shapes %s, %s do not fit a one-channel signal" %
+                                   (tuple(fw0.shape), tuple(fw1.shape)))
+            L_in, L = L, L + fw0.shape[2] - 1     # padding k - 1 on both sides lengthens the sequence (raw_ctcnet.py:57-61)
+            C0 = fw1.shape[0]
         if C0 != specs[0].ci:
             raise RuntimeError("wavenet_speech_amd: input has %d channels, first block expects %d" % (C0, specs[0].ci))
         for l in range(1, n):
@@ -179,7 +189,27 @@ class _HalfStackFn(torch.autograd.Function):
         flag = torch.zeros(1, dtype=torch.int32, device=dev) if mode.dtype == torch.float16 else None
         rs = float(lib.wn_hseries_residual_scale())
         cur = _hlease(mode, B, C0, layout, dev)
-        _load(lib, mode, x.detach().contiguous(), cur, layout, rs, None, flag)
+        ctx.front = None
+        if front is None:
+            _load(lib, mode, x.detach().contiguous(), cur, layout, rs, None, flag)
+        else:
+            # ---- feature layer in the series layout: the raw signal -> leaky(conv k) (elementwise kernel) -> leaky(conv 1x1) --------
+            F0, k0 = fw0.shape[0], fw0.shape[2]
+            xd = x.detach().contiguous()
+            f1 = _hlease(mode, B, F0, layout, dev)
+            _lib.check(lib.wn_hfeature_forward(mode.code, _p(xd), _p(fw0), _p(fb0), _p(f1), B, L_in, F0, k0, layout.ld, layout.halo,
+                                               ctypes.c_float(rs), ctypes.c_float(front[0]), _p(flag), _stream()), "wn_hfeature_forward")
+            fsh = _lib.ConvShape(B, L, F0, C0, 1, 1, 1, layout.ld, layout.halo)
+            nbytes = lib.wn_hconv_packed_bytes(ctypes.byref(fsh), mode.code)
+            if nbytes == 0:
+                _lib.check(-1, "wn_hconv_packed_bytes")
+            fpk = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.wn_hconv_pack(ctypes.byref(fsh), mode.code, _p(fw1), _p(fb1), ctypes.c_float(rs), _p(fpk), _stream()),
+                       "wn_hconv_pack")
+            _lib.check(lib.wn_hconv_forward_series(ctypes.byref(fsh), mode.code, _p(fpk), _p(f1), _p(cur), ctypes.c_float(rs),
+                                                   ctypes.c_float(front[1]), _p(flag), _stream()), "wn_hconv_forward_series")
+            if training:
+                ctx.front = (front, xd, f1, fsh, fpk, L_in, [tuple(t.shape) for t in front_params])
         ms = specs[0].ms
         S = torch.empty(B, ms, L, dtype=torch.float32, device=dev)
         saved, skip_w, skip_b = [], [], []
@@ -385,13 +415,19 @@ class _HalfStackFn(torch.autograd.Function):
             x, sg, z, packed, shape = ctx.saved[l]
             da, dg = _hlease(mode, B, spec.co, layout, dev), _hlease(mode, B, spec.co, layout, dev)
             dx = dxd = None
-            if l > 0:
+            if l > 0 or ctx.front is not None:
                 dx = _hlease(mode, B, spec.ci, layout, dev)
             elif ctx.needs_input_grad[0]:
                 dxd = dx0 = torch.empty(B, spec.ci, layout.length, dtype=torch.float32, device=dev)
-            _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
-                                                   _p(da), _p(dg), _p(dx), _p(dxd), _p(dyn_inv), _p(flag), _stream()),
-                       "wn_hblock_backward_data")
+            if l == 0 and ctx.front is not None:
+                # the stack's input is leaky(feature conv): its LeakyReLU backward rides in this block's dx epilogue (x = the stored activation)
+                _lib.check(lib.wn_hblock_backward_data_masked(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
+                                                              _p(da), _p(dg), _p(dx), _p(x), ctypes.c_float(ctx.front[0][1]), _p(flag),
+                                                              _stream()), "wn_hblock_backward_data_masked")
+            else:
+                _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
+                                                       _p(da), _p(dg), _p(dx), _p(dxd), _p(dyn_inv), _p(flag), _stream()),
+                           "wn_hblock_backward_data")
             k = spec.k
             shapes = [(spec.co, spec.ci, k), (spec.co,), (spec.co, spec.ci, k), (spec.co,), (spec.co, spec.co), (spec.co,),
                       (spec.ms, spec.co), (spec.ms,), (spec.co, spec.ci), (spec.co,)]
@@ -412,21 +448,52 @@ class _HalfStackFn(torch.autograd.Function):
             dr = dx
             ctx.saved[l] = None
         flush()
+        front_grads = []
+        if ctx.front is not None:
+            # ---- feature layer, backwards: dr is now the (masked) gradient of the stack's input, in the series ---------------------
+            (slope0, slope1), xd, f1, fsh, fpk, L_in, fshapes = ctx.front
+            rs = float(lib.wn_hseries_residual_scale())
+            F0 = fsh.in_channels
+            df1 = _hlease(mode, B, F0, layout, dev)
+            _lib.check(lib.wn_hconv_backward_data_series(ctypes.byref(fsh), mode.code, _p(fpk), _p(dr), _p(f1), ctypes.c_float(slope0),
+                                                         _p(df1), _p(flag), _stream()), "wn_hconv_backward_data_series")
+            dw1 = torch.empty(fshapes[2], dtype=torch.float32, device=dev)
+            db1 = torch.empty(fshapes[3], dtype=torch.float32, device=dev)
+            ws_bytes = lib.wn_hconv_wgrad_workspace_bytes(ctypes.byref(fsh), mode.code)
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            _lib.check(lib.wn_hconv_backward_weights(ctypes.byref(fsh), mode.code, _p(f1), _p(dr), ctypes.c_float(rs), _p(dw1), _p(db1),
+                                                     _p(dyn_inv), _p(ws), ws_bytes, _stream()), "wn_hconv_backward_weights")
+            k0 = fshapes[0][2]
+            dw0 = torch.empty(fshapes[0], dtype=torch.float32, device=dev)
+            db0 = torch.empty(fshapes[1], dtype=torch.float32, device=dev)
+            ws_bytes = lib.wn_hfeature_wgrad_workspace_bytes(B, L_in, F0, k0)
+            ws0 = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+            _lib.check(lib.wn_hfeature_backward_weights(mode.code, _p(xd), _p(df1), ctypes.c_float(1.0), _p(dw0), _p(db0), B, L_in, F0, k0,
+                                                        layout.ld, layout.halo, _p(dyn_inv), _p(ws0), ws_bytes, _stream()),
+                       "wn_hfeature_backward_weights")
+            front_grads = [dw0, db0, dw1, db1]
+            ctx.front = None
         _flags.WATCH.note(flag, _OVERFLOW_MSG % "backward pass", at_once=False)
         grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
-        return (dx0, None, None, None, None, None) + tuple(grads_flat) + tuple(head_grads)
+        return (dx0, None, None, None, None, None, None) + tuple(grads_flat) + tuple(head_grads) + tuple(front_grads)
 
 
-def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None):
+def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None, front=None):
     """head: None, or ((slope1, slope2), [w1, b1, w2, b2]) of an output block LeakyReLU, Conv1d 1x1, LeakyReLU, Conv1d 1x1 that is
-    to run inside the same function, in the half series: the result is then that block's output, not skips_sum."""
+    to run inside the same function, in the half series: the result is then that block's output, not skips_sum.
+    front: None, or ((slope0, slope1), [w0, b0, w1, b1]) of a feature layer Conv1d(1 -> F, k, padding k - 1), LeakyReLU, Conv1d 1x1,
+    LeakyReLU in front of the stack: x is then the raw one-channel signal [B, 1, L]."""
     if precision not in ("f16x3", "f16", "bf16"):
         raise ValueError("unknown precision %r" % (precision,))
-    if head is None:
-        return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, None, *flat_params)
-    slopes, hp = head
-    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache,
-                              (float(slopes[0]), float(slopes[1])), *(list(flat_params) + list(hp)))
+    flat = list(flat_params)
+    hs = fs = None
+    if head is not None:
+        hs = (float(head[0][0]), float(head[0][1]))
+        flat += list(head[1])
+    if front is not None:
+        fs = (float(front[0][0]), float(front[0][1]))
+        flat += list(front[1])
+    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, hs, fs, *flat)
 
 
 class _HalfConvFn(torch.autograd.Function):

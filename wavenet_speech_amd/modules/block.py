@@ -188,8 +188,38 @@ def fusable_head(head, precision):
     return (mods[0].negative_slope, mods[2].negative_slope), [mods[1].weight, mods[1].bias, mods[3].weight, mods[3].bias]
 
 
-def run_stack(out, blocks, bottlenecks, state=None, head=None):
+def fusable_front(front, precision, x):
+    """(slopes, parameters) of a feature layer that can run inside the half-precision stack function: exactly Conv1d(1 -> F, k,
+    padding k - 1), LeakyReLU, Conv1d 1x1, LeakyReLU (RawCTCNet.feature_layer, reference modules/raw_ctcnet.py:57-61) on a raw signal
+    that needs no gradient, in a mode whose entry convs follow the stack (pointwise_precision).  None otherwise."""
+    import os
+    import torch.nn as nn
+    knob = os.environ.get("WN_SERIES_FRONT", "1")
+    if front is None or knob == "0":
+        return None
+    # (WN_SERIES_FRONT=force: also in f16x3, whose entry convs otherwise stay exact fp32 -- the tests hold the fused feature layer
+    # to that mode's 1e-4 bar)
+    if precision == "f32" or (pointwise_precision(precision) != precision and knob != "force"):
+        return None
+    if x.requires_grad or x.dim() != 3 or x.shape[1] != 1:
+        return None
+    mods = list(front)
+    if len(mods) != 4 or not (isinstance(mods[1], nn.LeakyReLU) and isinstance(mods[3], nn.LeakyReLU)):
+        return None
+    c0, c1 = mods[0], mods[2]
+    if not (isinstance(c0, nn.Conv1d) and isinstance(c1, nn.Conv1d)) or c0.bias is None or c1.bias is None:
+        return None
+    k = c0.kernel_size[0]
+    if c0.in_channels != 1 or c0.stride != (1,) or c0.dilation != (1,) or c0.groups != 1 or c0.padding != (k - 1,) or k > 8:
+        return None
+    if c1.kernel_size != (1,) or c1.stride != (1,) or c1.padding != (0,) or c1.groups != 1:
+        return None
+    return (mods[1].negative_slope, mods[3].negative_slope), [c0.weight, c0.bias, c1.weight, c1.bias]
+
+
+def run_stack(out, blocks, bottlenecks, state=None, head=None, front=None):
     """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path.
+    `front`: the result of fusable_front() (the feature layer then runs inside the function and `out` is the raw signal).
     With `head` (the model's output block) returns (tensor, head_done): in the half modes the output block runs inside the same
     function, in the series layout (no dense fp32 skips_sum, no separate LeakyReLU passes), and `tensor` is its output."""
     specs, flat = [], []
@@ -214,5 +244,5 @@ def run_stack(out, blocks, bottlenecks, state=None, head=None):
         specs.append(blk.spec(out_dim))
         flat.extend(blk.hip_params(w, b))
     fh = fusable_head(head, precision)
-    res = HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache, head=fh)
+    res = HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache, head=fh, front=front)
     return res if head is None else (res, fh is not None)

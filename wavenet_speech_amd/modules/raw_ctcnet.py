@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import ResidualBlock, StackState, run_stack, pointwise_precision, head_precision
+from .block import ResidualBlock, StackState, run_stack, pointwise_precision, head_precision, fusable_front
 from .pointwise import run_sequential
 
 
@@ -56,12 +56,19 @@ class RawCTCNet(nn.Module):
                     noisy_zero(p)
 
     def forward(self, seq):
-        out = run_sequential(self.feature_layer, seq, pointwise_precision(self.stack_state.precision))
+        # half modes: feature layer, stack and output block are ONE function in the series layout (no dense round trips, no
+        # separate LeakyReLU passes); the position mixer, a signal that needs a gradient or exact-fp32 entry convs keep the op-by-op form
+        front = None if self.positions else fusable_front(self.feature_layer, self.stack_state.precision, seq)
+        if front is not None:
+            out = seq
+        else:
+            out = run_sequential(self.feature_layer, seq, pointwise_precision(self.stack_state.precision))
         if self.positions:
             steps = torch.arange(0., out.size(2), device=seq.device).view(1, 1, -1)
             out = out + run_sequential(self.positions_conv1x1, steps, pointwise_precision(self.stack_state.precision))
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
-                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state, head=self.output_block)
+                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state, head=self.output_block,
+                              front=front)
         skips_sum, done = skips_sum
         logit_seq = skips_sum if done else run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
