@@ -162,12 +162,18 @@ class _ResidualStackFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, specs, grad_enabled, pack_cache, *flat):
+    def forward(ctx, x, specs, grad_enabled, pack_cache, pool, *flat):
+        """pool > 1: AvgPool1d(pool) of x (reference modules/classifier.py:53,102) fused into the load of the stack's input series"""
         lib = _lib.load()
         _require_device(x, "input")
         n = len(specs)
         assert len(flat) == n * PARAMS_PER_BLOCK
         B, C0, L = x.shape
+        ctx.pool, ctx.in_length = int(pool), L
+        if pool > 1:
+            L = L // pool
+            if L < 1:
+                raise RuntimeError("wavenet_speech_amd: sequence shorter than the pooling window")
         if C0 != specs[0].ci:
             raise RuntimeError("wavenet_speech_amd: input has %d channels, first block expects %d" % (C0, specs[0].ci))
         for l in range(1, n):
@@ -181,7 +187,11 @@ class _ResidualStackFn(torch.autograd.Function):
         training = bool(grad_enabled) and any(ctx.needs_input_grad)
         ctx.training = training
         cur = Lease(B, C0, layout, dev)
-        load_series(cur.t, x.detach(), layout)
+        if pool > 1:
+            _lib.check(lib.wn_series_load_pooled(_p(x.detach().contiguous()), _p(cur), B, C0, ctx.in_length, int(pool), layout.ld,
+                                                 layout.halo, _stream()), "wn_series_load_pooled")
+        else:
+            load_series(cur.t, x.detach(), layout)
         ms = specs[0].ms
         S = fresh_series(B, ms, layout, dev)
         saved, skip_w, skip_b = [], [], []
@@ -240,10 +250,20 @@ class _ResidualStackFn(torch.autograd.Function):
             grads_flat[l * PARAMS_PER_BLOCK:(l + 1) * PARAMS_PER_BLOCK] = grads
             dr = dx
             ctx.saved[l] = None  # release this block's activations to the pool
-        dx0 = window(dr.t, specs[0].ci, layout).clone() if ctx.needs_input_grad[0] else None
+        dx0 = window(dr.t, specs[0].ci, layout).clone(memory_format=torch.contiguous_format) if ctx.needs_input_grad[0] else None
+        if dx0 is not None and ctx.pool > 1:
+            dx0 = _unpool(lib, dx0, ctx.in_length, ctx.pool)
         # 1x1 Conv1d weights come in as [Co][Ci][1]; hand each gradient back in its parameter's own shape
         grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
-        return (dx0, None, None, None) + tuple(grads_flat)
+        return (dx0, None, None, None, None) + tuple(grads_flat)
+
+
+def _unpool(lib, dpooled, length, pool):
+    """backward of the pooled load: each pooled gradient / pool, broadcast to its pool columns (0 for a dropped tail)"""
+    B, C, _ = dpooled.shape
+    dx = torch.empty(B, C, length, dtype=torch.float32, device=dpooled.device)
+    _lib.check(lib.wn_pool_backward(_p(dpooled.contiguous()), _p(dx), B, C, length, int(pool), _stream()), "wn_pool_backward")
+    return dx
 
 
 class PackCache(object):
@@ -281,16 +301,16 @@ class PackCache(object):
         return t
 
 
-def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None, head=None, front=None):
+def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None, head=None, front=None, pool=1):
     """skips_sum of a stack of residual blocks.  flat_params: 10 tensors per block in C-ABI order
     (w_tanh, b_tanh, w_sigmoid, b_sigmoid, w_res [Co,Co,1], b_res, w_skip [Ms,Co], b_skip, w_proj, b_proj).
     precision: "f32" (exact fp32 MFMA, default) or one of the half-precision MFMA modes of functional_half."""
     if precision != "f32":
         from . import functional_half
-        return functional_half.residual_stack(x, specs, flat_params, precision, pack_cache, head, front)
+        return functional_half.residual_stack(x, specs, flat_params, precision, pack_cache, head, front, pool)
     if head is not None or front is not None:
         raise ValueError("the fused output block / feature layer exist in the half-precision modes only")
-    return _ResidualStackFn.apply(x, tuple(specs), torch.is_grad_enabled(), pack_cache, *flat_params)
+    return _ResidualStackFn.apply(x, tuple(specs), torch.is_grad_enabled(), pack_cache, int(pool), *flat_params)
 
 
 class _ResidualBlockFn(torch.autograd.Function):

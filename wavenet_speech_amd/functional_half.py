@@ -153,7 +153,7 @@ class _HalfStackFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of_first_tensor
-    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, head, front, *flat):
+    def forward(ctx, x, specs, mode, grad_enabled, pack_cache, head, front, pool, *flat):
         """head: None, or (slope1, slope2) of an output block LeakyReLU(slope1), Conv1d 1x1, LeakyReLU(slope2), Conv1d 1x1
         (modules/wavenet.py:67-71, raw_ctcnet.py:89-93) whose parameters (w1, b1, w2, b2) are the last four tensors of `flat`:
         the block then runs inside this function, in the half series, and the function returns its output instead of skips_sum."""
@@ -170,6 +170,13 @@ class _HalfStackFn(torch.autograd.Function):
             flat = flat[:-4]
         assert len(flat) == n * PARAMS_PER_BLOCK
         B, C0, L = x.shape
+        ctx.pool, ctx.in_length = int(pool), L
+        if pool > 1:               # AvgPool1d(pool) of x (reference modules/classifier.py:53,102) fused into the load of the input series
+            if front is not None:
+                raise RuntimeError("wavenet_speech_amd: pooling and a feature layer in front of one stack are not combined")
+            L = L // pool
+            if L < 1:
+                raise RuntimeError("wavenet_speech_amd: sequence shorter than the pooling window")
         if front is not None:
             fw0, fb0, fw1, fb1 = front_params
             if C0 != 1 or fw0.shape[1] != 1 or fw1.shape[2] != 1 or fw1.shape[1] != fw0.shape[0]:
@@ -190,7 +197,11 @@ class _HalfStackFn(torch.autograd.Function):
         rs = float(lib.wn_hseries_residual_scale())
         cur = _hlease(mode, B, C0, layout, dev)
         ctx.front = None
-        if front is None:
+        if front is None and pool > 1:
+            _lib.check(lib.wn_hseries_load_pooled(mode.code, _p(x.detach().contiguous()), _p(cur), B, C0, ctx.in_length, int(pool),
+                                                  layout.ld, layout.halo, ctypes.c_float(rs), None, _p(flag), _stream()),
+                       "wn_hseries_load_pooled")
+        elif front is None:
             _load(lib, mode, x.detach().contiguous(), cur, layout, rs, None, flag)
         else:
             # ---- feature layer in the series layout: the raw signal -> leaky(conv k) (elementwise kernel) -> leaky(conv 1x1) --------
@@ -475,10 +486,13 @@ class _HalfStackFn(torch.autograd.Function):
             ctx.front = None
         _flags.WATCH.note(flag, _OVERFLOW_MSG % "backward pass", at_once=False)
         grads_flat = [None if g is None else g.view(shp) for g, shp in zip(grads_flat, ctx.param_shapes)]
-        return (dx0, None, None, None, None, None, None) + tuple(grads_flat) + tuple(head_grads) + tuple(front_grads)
+        if dx0 is not None and ctx.pool > 1:
+            from .functional import _unpool
+            dx0 = _unpool(lib, dx0, ctx.in_length, ctx.pool)
+        return (dx0, None, None, None, None, None, None, None) + tuple(grads_flat) + tuple(head_grads) + tuple(front_grads)
 
 
-def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None, front=None):
+def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None, front=None, pool=1):
     """head: None, or ((slope1, slope2), [w1, b1, w2, b2]) of an output block LeakyReLU, Conv1d 1x1, LeakyReLU, Conv1d 1x1 that is
     to run inside the same function, in the half series: the result is then that block's output, not skips_sum.
     front: None, or ((slope0, slope1), [w0, b0, w1, b1]) of a feature layer Conv1d(1 -> F, k, padding k - 1), LeakyReLU, Conv1d 1x1,
@@ -493,7 +507,7 @@ def residual_stack(x, specs, flat_params, precision, pack_cache=None, head=None,
     if front is not None:
         fs = (float(front[0][0]), float(front[0][1]))
         flat += list(front[1])
-    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, hs, fs, *flat)
+    return _HalfStackFn.apply(x, tuple(specs), _Mode(precision), torch.is_grad_enabled(), pack_cache, hs, fs, int(pool), *flat)
 
 
 class _HalfConvFn(torch.autograd.Function):

@@ -217,8 +217,9 @@ def fusable_front(front, precision, x):
     return (mods[1].negative_slope, mods[3].negative_slope), [c0.weight, c0.bias, c1.weight, c1.bias]
 
 
-def run_stack(out, blocks, bottlenecks, state=None, head=None, front=None):
+def run_stack(out, blocks, bottlenecks, state=None, head=None, front=None, pool=1):
     """skips_sum over `blocks` (reference modules/wavenet.py:98-100) through the fused HIP stack path.
+    `pool` > 1: AvgPool1d(pool) of `out` fused into the load of the stack's input (WaveNetClassifier.mean_pool).
     `front`: the result of fusable_front() (the feature layer then runs inside the function and `out` is the raw signal).
     With `head` (the model's output block) returns (tensor, head_done): in the half modes the output block runs inside the same
     function, in the series layout (no dense fp32 skips_sum, no separate LeakyReLU passes), and `tensor` is its output."""
@@ -244,5 +245,5 @@ def run_stack(out, blocks, bottlenecks, state=None, head=None, front=None):
         specs.append(blk.spec(out_dim))
         flat.extend(blk.hip_params(w, b))
     fh = fusable_head(head, precision)
-    res = HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache, head=fh, front=front)
+    res = HF.residual_stack(out, specs, flat, precision=precision, pack_cache=cache, head=fh, front=front, pool=pool)
     return res if head is None else (res, fh is not None)

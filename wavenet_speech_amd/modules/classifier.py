@@ -39,9 +39,16 @@ class WaveNetClassifier(nn.Module):
                 p.data.zero_()
 
     def forward(self, seq):
-        out = self.mean_pool(seq)
+        # mean_pool (reference modules/classifier.py:53,102: AvgPool1d, no padding, the tail that does not fill a window dropped)
+        # is fused into the load of the stack's input series and its backward into the scatter of the input gradient; the
+        # nn.AvgPool1d member stays for the reference's attribute surface.  (WN_POOL_FUSED=0: the torch op, then a plain load.)
+        import os
+        k = self.mean_pool.kernel_size if isinstance(self.mean_pool.kernel_size, int) else self.mean_pool.kernel_size[0]
+        fused = os.environ.get("WN_POOL_FUSED", "1") != "0" and seq.is_cuda
+        out = seq if fused else self.mean_pool(seq)
         skips_sum = run_stack(out, [self.input_block] + list(self.convolutions),
-                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state, head=self.output_block)
+                              [self.input_skip_bottleneck] + list(self.bottlenecks), self.stack_state, head=self.output_block,
+                              pool=k if fused else 1)
         skips_sum, done = skips_sum
         logit_seq = skips_sum if done else run_sequential(self.output_block, skips_sum, head_precision(self.stack_state.precision))
         if not self.softmax:
