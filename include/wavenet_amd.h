@@ -264,6 +264,10 @@ int wn_hseries_load(int precision, const float* dense, void* series, int batch, 
 
 size_t wn_hblock_packed_bytes(const wn_block_shape* s, int precision);
 int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream);
+/* the same; *overflow_flag (DEVICE unsigned, caller-zeroed, may be NULL) is set when a weight leaves fp16's range after its
+ * built-in scale (256 * w / input scale: |w| >= 16 for gate / projection weights) -- the gate would saturate silently otherwise */
+int wn_hblock_pack_checked(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, unsigned* overflow_flag,
+                           wn_stream_t stream);
 /* x, r_out (nullable), sg (nullable: inference), z: half series.  z = tanh(a) sigmoid(g) and sg = sigmoid(g) are what the
  * backward pass needs (the tanh is recovered as z / sg: one tensor less to write and to keep).  skip_dense (nullable): dense
  * fp32 [B][Ms][L] that receives (skip_accumulate: += ) W_skip z + b_skip -- the per-block form used for inference.
@@ -336,6 +340,10 @@ int wn_hseries_load_pooled(int precision, const float* dense, void* series, int 
 int wn_series_load_pooled(const float* dense, float* series, int batch, int channels, int length, int pool, int ld, int halo,
                           wn_stream_t stream);
 int wn_pool_backward(const float* dpooled, float* dx, int batch, int channels, int length, int pool, wn_stream_t stream);
+/* the dynamic gradient scale of a backward call in the fp16 modes: scale_and_inverse[0] = 2^floor(log2(target / max|x|)) (clamped to
+ * 2^+-100), [1] = its reciprocal -- device floats, no host synchronisation.  `accumulator`: one DEVICE unsigned, zero before the
+ * first call (the call leaves it zero again).  x 16-byte aligned. */
+int wn_grad_scale(const float* x, long long count, float target, float* scale_and_inverse, unsigned* accumulator, wn_stream_t stream);
 
 /* The weight gradients of SEVERAL blocks of one series geometry in one launch (+ one reduction): blocks of <= 128 channels are
  * two or three gradient tiles each, so per-block launches are short split-K jobs dominated by their partial slabs; keep the
@@ -368,7 +376,7 @@ int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_para
                                size_t* block_offsets, size_t* skipsum_offsets, size_t* packed_total, int* njobs,
                                int* launch_blocks);
 int wn_hstack_pack_run(const void* table_dev, int nblocks, int njobs, int launch_blocks, const void* const* dynamic_bases,
-                       int ndynamic, void* packed, wn_stream_t stream);
+                       int ndynamic, void* packed, unsigned* overflow_flag /* as wn_hblock_pack_checked */, wn_stream_t stream);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of every kernel on its launch stream ----
  * Kernel classes: index into wn_prof_kernel_name().  wn_prof_collect() synchronises the recorded

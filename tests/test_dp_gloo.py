@@ -46,14 +46,15 @@ def _worker(rank, world, port, out, async_op=False):
         handle.wait()                            # idempotent
     else:
         sync.reduce()
-    # every gradient is still a view of the flat buffer, and all ranks agree bit for bit
-    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    # every gradient is still a view of the flat buffer (a parameter that got none keeps None: a weight-decay optimizer must not start
+    # moving what the single-process path never touches), and all ranks agree bit for bit
+    assert all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     flat = sync.flat.clone()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     assert all(torch.equal(gathered[0], t) for t in gathered)
     if rank == 0:
-        torch.save({k: p.grad.clone() for k, p in params.items()}, out)
+        torch.save({k: p.grad.clone() for k, p in params.items() if p.grad is not None}, out)
     dist.destroy_process_group()
 
 
@@ -74,6 +75,7 @@ def test_two_rank_allreduce_matches_single_process(tmp_path):
     _loss(params, x, cot).backward()             # single process, whole batch, loss averaged over it
     for k, p in params.items():
         if p.grad is None:
+            assert k not in got, k             # None on the single-process path <=> None after the data-parallel reduce
             continue
         assert O.rel_err(got[k], p.grad) < 1e-5, k
 
@@ -108,7 +110,7 @@ def test_flat_buffer_single_process_semantics():
     assert all(p.grad is None for p in sync.params)
     _loss(params, x, cot).backward()
     sync.reduce()
-    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    assert all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
     for k in params:
         if ref[k].grad is not None:
             assert torch.equal(params[k].grad, ref[k].grad)

@@ -287,3 +287,28 @@ def test_f16x3_wide_stack_multi_slab():
     g = torch.Generator().manual_seed(32)
     x, cot = torch.randn(1, c, 700, generator=g), torch.randn(1, c, 700, generator=g)
     _run(net, x, cot, layers, "f16x3", TOL)
+
+
+def test_fp16_weight_beyond_range_is_loud():
+    """weights are packed as 256 * 16 * w in the fp16 modes, so |w| >= 16 becomes inf and inf * 0 = NaN downstream; the
+    store-side checks are written !(|v| <= 65504) so that the NaN trips the overflow flag instead of passing silently"""
+    layers = [(32, 32, 2, 1), (32, 32, 2, 2)]
+    net = _cond_wavenet(32, layers, seed=3).to(DEV)
+    W.set_precision(net, "f16")
+    with torch.no_grad():
+        net.convolutions[0].conv_tanh.conv1d.weight[3, 5, 1] = 32.0
+        with pytest.raises(RuntimeError, match="fp16 overflow"):
+            net(torch.randn(1, 32, 200, device=DEV))
+            W.check_device_flags()
+
+
+def test_grad_scale_kernel_matches_the_torch_expression():
+    from wavenet_speech_amd import functional_half as FH
+    mode = FH._Mode("f16")
+    for n, mag in ((1000003, 3.7), (64, 1e-12), (5, 7e9), (4096, 0.0)):
+        x = torch.randn(n, device=DEV) * mag
+        dyn, inv = FH._grad_scale(x, mode)
+        amax = x.abs().amax().clamp_min(1e-30)
+        want = torch.exp2(torch.floor(torch.log2(FH.GRAD_TARGET / amax)).clamp(-100.0, 100.0))
+        assert float(dyn) == float(want), (n, mag, float(dyn), float(want))
+        assert float(inv) == 1.0 / float(want)

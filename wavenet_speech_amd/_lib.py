@@ -86,6 +86,7 @@ SIGNATURES = {
                                 c_void_p]),
     "wn_hblock_packed_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_pack": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p]),
+    "wn_hblock_pack_checked": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p, c_void_p]),
     "wn_hblock_forward_is_fused": (c_int, [POINTER(BlockShape), c_int]),
     "wn_hblock_forward": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "wn_hseries_load_pooled": (c_int, [c_int, c_float_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float_p, c_void_p,
                                        c_void_p]),
     "wn_series_load_pooled": (c_int, [c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wn_grad_scale": (c_int, [c_float_p, c_longlong, c_float, c_float_p, c_void_p, c_void_p]),
     "wn_pool_backward": (c_int, [c_float_p, c_float_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wn_hskipsum_forward_series": (c_int, [POINTER(SkipSumShape), c_int, c_void_p, POINTER(c_void_p), c_void_p, c_float, c_float, c_void_p,
                                            c_void_p]),
@@ -119,7 +121,7 @@ SIGNATURES = {
     "wn_hstack_pack_table_build": (c_int, [POINTER(BlockShape), POINTER(BlockParams), c_int, c_int, c_int, POINTER(MemRange), c_int,
                                            c_void_p, c_size_t, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t),
                                            POINTER(c_int), POINTER(c_int)]),
-    "wn_hstack_pack_run": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "wn_hstack_pack_run": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p), c_int, c_void_p, c_void_p, c_void_p]),
     "wn_hblock_wgrad_workspace_bytes": (c_size_t, [POINTER(BlockShape), c_int]),
     "wn_hblock_backward_weights": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, POINTER(BlockParams), c_float_p, c_void_p, c_size_t, c_void_p]),

@@ -232,6 +232,34 @@ __global__ __launch_bounds__(256) void pool_unload_kernel(const PoolArgs a) {
     a.dense[idx] = tp < a.Lp ? a.src[((long long)b * a.C + c) * a.Lp + tp] / (float)a.pool : 0.0f;
 }
 
+// ---- dynamic power-of-two gradient scale of the fp16 modes ------------------------------------------------------------------------
+// scale = 2^floor(log2(target / max|x|)), clamped to 2^+-100, and its reciprocal, as two device floats: one read of x (the torch
+// expression it replaces -- abs, amax, clamp, div, log2, floor, clamp, exp2, reciprocal -- was nine launches and wrote |x| out).
+// max is order-independent: an integer atomicMax on the bit pattern of |x| (monotonic for non-negative floats) is deterministic.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ acc) {
+    const long long n4 = n >> 2;
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                                               __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = __builtin_fmaxf(m, __builtin_fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(acc, __builtin_bit_cast(unsigned, m));   // NaN bit patterns order above inf: they win, as in torch
+}
+
+__global__ void grad_scale_kernel(unsigned* acc, float target, float* out) {
+    const float amax = __builtin_fmaxf(__builtin_bit_cast(float, acc[0]), 1e-30f);
+    float e = __builtin_floorf(__builtin_log2f(target / amax));
+    e = __builtin_fminf(__builtin_fmaxf(e, -100.0f), 100.0f);
+    const float s = __builtin_exp2f(e);
+    out[0] = s;
+    out[1] = 1.0f / s;
+    acc[0] = 0;                                                   // ready for the next call
+}
+
 }  // namespace wn
 
 namespace wn {
@@ -371,5 +399,19 @@ int wn_pool_backward(const float* dpooled, float* dx, int batch, int channels, i
     hipLaunchKernelGGL(pool_unload_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail_shared(e, "pool_unload");
+    return WN_OK;
+}
+
+int wn_grad_scale(const float* x, long long count, float target, float* scale_and_inverse, unsigned* accumulator, wn_stream_t stream) {
+    if (!x || !scale_and_inverse || !accumulator) return WN_ERR_NULL;
+    if (count <= 0 || !(target > 0.0f) || (reinterpret_cast<uintptr_t>(x) & 15)) return WN_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const long long n4 = count / 4;
+    const unsigned grid = (unsigned)(n4 / 256 < 1 ? 1 : (n4 / 256 > 2048 ? 2048 : n4 / 256));
+    ProfScopeShared prof(KC_FRONT, 0.0, st);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, count, accumulator);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, accumulator, target, scale_and_inverse);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail_shared(e, "grad_scale");
     return WN_OK;
 }

@@ -104,6 +104,7 @@ struct HPackSet {
 struct HPackDyn {
     const char* base[3];
     char* out;              // table jobs: HPackArgs::wpacked / ::bias are byte offsets from here
+    unsigned* flag;         // set to 1 when a scaled weight leaves fp16's range (fp16 modes; may be nullptr)
 };
 struct HPackArgs {
     HPackSet set[2];
@@ -118,6 +119,7 @@ struct HPackArgs {
     char* wpacked;
     float* bias;
     long long total_units;          // 16-byte units per plane over all slabs
+    unsigned* flag;                 // direct launches: as HPackDyn::flag
 };
 static_assert(sizeof(HPackArgs) <= 4096, "HPackArgs travels as a kernel argument");
 

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void hload_kernel(const HLoadArgs a) {
         const int c = 8 * g + j;
         v[j] = c < a.C ? a.src[((long long)b * a.C + c) * a.L + t] * s : 0.0f;
         hi[j] = (T)v[j];
-        if (!BF) ovf |= (__builtin_fabsf(v[j]) > 65504.0f) ? 1u : 0u;
+        if (!BF) ovf |= (!(__builtin_fabsf(v[j]) <= 65504.0f)) ? 1u : 0u;
     }
     hi = pin(hi);   // see store4: the remainder must be taken against the stored bits
 #pragma unroll
@@ -131,6 +131,13 @@ __device__ __forceinline__ void hpack_body(const HPackArgs& a, const HPackDyn& d
             for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
             *reinterpret_cast<b8*>(dp) = hi;
         } else {
+            // weights are packed as 256 * w / (input scale): |w| >= 16 (gate, proj, conv weights of 1/16-scaled inputs) or >= 256 leaves
+            // fp16's range and would saturate the gate silently (tanh(inf) = 1) -- say so instead
+            unsigned ovf = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ovf |= (!(__builtin_fabsf(v[j]) <= 65504.0f)) ? 1u : 0u;
+            unsigned* fl = TABLE ? d.flag : a.flag;
+            if (ovf && fl) atomicOr(fl, 1u);
             h8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) hi[j] = (_Float16)v[j];
@@ -164,7 +171,7 @@ __device__ __forceinline__ void hpack_body(const HPackArgs& a, const HPackDyn& d
 }
 
 __global__ __launch_bounds__(256) void hpack_kernel(const HPackArgs a) {
-    const HPackDyn d = {{nullptr, nullptr, nullptr}, nullptr};
+    const HPackDyn d = {{nullptr, nullptr, nullptr}, nullptr, nullptr};
     hpack_body<false>(a, d, a.wpacked, a.bias, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 

@@ -444,14 +444,22 @@ int fill_hblock_jobs(const wn_block_shape* s, int precision, const wn_block_para
 }
 }  // namespace
 
-int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream) {
+int wn_hblock_pack_checked(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, unsigned* overflow_flag,
+                           wn_stream_t stream) {
     std::vector<HPackArgs> jobs;
     int rc = fill_hblock_jobs(s, precision, p, packed, jobs);
     if (rc != WN_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     wn::ProfScopeShared prof(KC_PACK, 0.0, st);
-    for (const HPackArgs& a : jobs) WN_HIP(launch_hpack(a, st), "hpack(block)");
+    for (HPackArgs& a : jobs) {
+        a.flag = overflow_flag;
+        WN_HIP(launch_hpack(a, st), "hpack(block)");
+    }
     return WN_OK;
+}
+
+int wn_hblock_pack(const wn_block_shape* s, int precision, const wn_block_params* p, void* packed, wn_stream_t stream) {
+    return wn_hblock_pack_checked(s, precision, p, packed, nullptr, stream);
 }
 
 int wn_hblock_forward_is_fused(const wn_block_shape* s, int precision) {
@@ -810,7 +818,7 @@ int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_para
 }
 
 int wn_hstack_pack_run(const void* table_dev, int nblocks, int njobs, int launch_blocks, const void* const* dynamic_bases, int ndynamic,
-                       void* packed, wn_stream_t stream) {
+                       void* packed, unsigned* overflow_flag, wn_stream_t stream) {
     if (!table_dev || !packed) return WN_ERR_NULL;
     if (nblocks <= 0 || njobs <= 0 || njobs > stack_jobs_upper_bound(nblocks) || launch_blocks <= 0 || ndynamic < 0 ||
         ndynamic > kMaxDynamic || (ndynamic && !dynamic_bases))
@@ -819,6 +827,7 @@ int wn_hstack_pack_run(const void* table_dev, int nblocks, int njobs, int launch
     std::memset(&d, 0, sizeof(d));
     for (int i = 0; i < ndynamic; ++i) d.base[i] = (const char*)dynamic_bases[i];
     d.out = (char*)packed;
+    d.flag = overflow_flag;
     const HPackArgs* jobs = reinterpret_cast<const HPackArgs*>(table_dev);
     const int* block0 = reinterpret_cast<const int*>((const char*)table_dev + align256((size_t)stack_jobs_upper_bound(nblocks) * sizeof(HPackArgs)));
     hipStream_t st = (hipStream_t)stream;

@@ -53,9 +53,10 @@ __device__ __forceinline__ void store4(char* p, long long pstride, const float (
     for (int q = 0; q < 4; ++q) hi[q] = (T)v[q];
     if constexpr (P == 2) hi = pin(hi);
     *reinterpret_cast<V4*>(p) = hi;
+    // (written as !(|v| <= max) so that a NaN trips it too: weights beyond fp16's range pack to inf and inf * 0 = NaN downstream)
     if constexpr (!BF && CHK) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ovf |= (__builtin_fabsf(v[q]) > 65504.0f) ? 1u : 0u;
+        for (int q = 0; q < 4; ++q) ovf |= (!(__builtin_fabsf(v[q]) <= 65504.0f)) ? 1u : 0u;
     }
     if constexpr (P == 2) {
         V4 lo;

@@ -70,14 +70,25 @@ def check_fp16_overflow():
     _flags.check_device_flags()
 
 
+_SCALE_ACC = {}      # per device: the absmax accumulator of wn_grad_scale
+
+
 def _grad_scale(cotangent, mode):
     """(scale, 1 / scale) device scalars of a backward call: the dynamic power of two that puts max|cotangent| at GRAD_TARGET,
     computed on the device (no host sync).  bf16 has fp32's exponent range: its gradients need no scaling (None, None)."""
     if mode.dtype == torch.bfloat16:
         return None, None
-    amax = cotangent.abs().amax().clamp_min(1e-30)
-    dyn = torch.exp2(torch.floor(torch.log2(GRAD_TARGET / amax)).clamp(-100.0, 100.0)).reshape(1).to(torch.float32)
-    return dyn, (1.0 / dyn).contiguous()
+    lib = _lib.load()
+    dev = cotangent.device
+    acc = _SCALE_ACC.get(dev)
+    if acc is None:
+        acc = _SCALE_ACC[dev] = torch.zeros(1, dtype=torch.int32, device=dev)   # (every call leaves it zero again)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    c = cotangent.contiguous()
+    if c.data_ptr() % 16:
+        c = c.clone()                     # (a view into the middle of a buffer: the kernel reads 16-byte vectors)
+    _lib.check(lib.wn_grad_scale(_p(c), c.numel(), ctypes.c_float(GRAD_TARGET), _p(out), _p(acc), _stream()), "wn_grad_scale")
+    return out[0:1], out[1:2]
 
 
 def _load(lib, mode, dense, lease, layout, scale, dyn, flag):
@@ -139,12 +150,12 @@ class StackPackTable(object):
         self.skipsum_offsets = list(soffs)
         self.total = total.value
 
-    def run(self, lib, storages, device):
+    def run(self, lib, storages, device, flag=None):
         """pack everything into a fresh buffer; returns it (block l at data_ptr() + block_offsets[l])"""
         packed = torch.empty(self.total, dtype=torch.uint8, device=device)
         bases = (ctypes.c_void_p * max(1, self.ndyn))(*[st.data_ptr() for st in storages])
         _lib.check(lib.wn_hstack_pack_run(_p(self.table), self.nblk, self.njobs, self.launch_blocks, bases, self.ndyn, _p(packed),
-                                          _stream()), "wn_hstack_pack_run")
+                                          _p(flag), _stream()), "wn_hstack_pack_run")
         return packed
 
 
@@ -247,7 +258,7 @@ class _HalfStackFn(torch.autograd.Function):
                         pack_cache.tables.clear()
                     pack_cache.tables[key] = table
                 if table:
-                    packed_all = table.run(lib, storages, dev)
+                    packed_all = table.run(lib, storages, dev, flag)
                 else:
                     table = None
         for l, spec in enumerate(specs):
@@ -263,8 +274,8 @@ class _HalfStackFn(torch.autograd.Function):
                     _lib.check(-1, "wn_hblock_packed_bytes")
                 packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 ps = _params_struct(params)
-                _lib.check(lib.wn_hblock_pack(ctypes.byref(shape), mode.code, ctypes.byref(ps), _p(packed), _stream()),
-                           "wn_hblock_pack")
+                _lib.check(lib.wn_hblock_pack_checked(ctypes.byref(shape), mode.code, ctypes.byref(ps), _p(packed), _p(flag), _stream()),
+                           "wn_hblock_pack_checked")
                 if pack_cache is not None and pack_cache.frozen and not grad_enabled:
                     pack_cache.put(l, layout, B, packed)
             r = _hlease(mode, B, spec.co, layout, dev) if l + 1 < n else None

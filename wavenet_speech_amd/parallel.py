@@ -74,18 +74,24 @@ class FlatGradAllReduce(object):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def gather(self):
-        """copy the freshly computed gradients into the flat buffer and re-point p.grad at the buffer"""
-        src, dst = [], []
+        """copy the freshly computed gradients into the flat buffer and re-point p.grad at the buffer.  A parameter that received NO
+        gradient this step (the last block's unused residual path: autograd leaves it None in the reference too) keeps
+        p.grad = None -- replicas are identical, so it is None on every rank -- and only its slice of the flat buffer is zeroed:
+        a weight-decay optimizer must not start moving parameters the single-process path never touches."""
+        src, dst, live = [], [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()                     # parameter did not take part in this step
-            elif p.grad.data_ptr() != v.data_ptr():
+                live.append(False)
+                continue
+            live.append(True)
+            if p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        for p, v, on in zip(self.params, self.views, live):
+            p.grad = v if on else None
 
     def reduce(self, async_op=False):
         """gather + all-reduce (+ 1/world).  async_op=True returns a handle whose wait() completes the collective AND
