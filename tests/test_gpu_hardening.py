@@ -103,13 +103,17 @@ def test_last_block_residual_path_gets_no_gradient():
     assert last.conv_tanh.conv1d.weight.grad is not None and last.conv1x1_skip.weight.grad is not None
     first = net.convolutions[0]
     assert first.conv1x1_residual.weight.grad is not None and first.residual_proj.weight.grad is not None
-    # the flat-gradient buffer of the data-parallel wrapper zero-fills such parameters
+    # the data-parallel wrapper keeps them None too (only their slice of the flat buffer is zeroed for the all-reduce): a
+    # weight-decay optimizer then treats them exactly as on the single-process path
     from wavenet_speech_amd.parallel import FlatGradAllReduce
     sync = FlatGradAllReduce(net.parameters())
     sync.zero()
     net(x).sum().backward()
     sync.reduce()
-    assert float(last.residual_proj.weight.grad.abs().max()) == 0.0
+    assert last.residual_proj.weight.grad is None and last.conv1x1_residual.bias.grad is None
+    assert first.residual_proj.weight.grad is not None
+    i = [id(p) for p in sync.params].index(id(last.residual_proj.weight))
+    assert float(sync.views[i].abs().max()) == 0.0
 
 
 def test_mis_chained_stack_is_an_error():
