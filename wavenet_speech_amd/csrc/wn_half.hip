@@ -414,18 +414,22 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     if constexpr (PRE && EPI == HEPI_STORE) {
         const HDst d = a.dst[sl.dst];
         if (full_cols && sl.row0 + ROWS <= d.cp) {
-            char* dbase = d.base + (long long)b * d.ustride + ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+            // row groups in pairs (i, i + 1): 16-byte stores, lanes 0-31 the unit of group i, lanes 32-63 that of group i + 1 (store8)
+            char* dbase = d.base + (long long)b * d.ustride + ((long long)a.halo + t0 + wn * 128 + r) * 16;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    char* prow = dbase + (long long)((sl.row0 + rowbase + 32 * m + 8 * i) >> 3) * ld * 16;
+                for (int i = 0; i < 4; i += 2) {
+                    char* prow = dbase + (long long)(((sl.row0 + rowbase + 32 * m + 8 * i) >> 3) + h) * ld * 16;
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        float v[4];
+                        float va[4], vb[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = acc[m][n][4 * i + q] * osc + bvec[m][i][q];
-                        store4<P, BF>(prow + n * 512, d.pstride, v, ovf);
+                        for (int q = 0; q < 4; ++q) {
+                            va[q] = acc[m][n][4 * i + q] * osc + bvec[m][i][q];
+                            vb[q] = acc[m][n][4 * i + 4 + q] * osc + bvec[m][i + 1][q];
+                        }
+                        store8<P, BF>(prow + n * 512, d.pstride, va, vb, ovf);
                     }
                 }
             if constexpr (!BF) {
@@ -435,31 +439,88 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
         }
     } else if constexpr (PRE && EPI == HEPI_GATE) {
         if (full_cols && sl.row0 + ROWS / 2 <= a.gate_rows) {
-            long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16 + 8 * h;
+            long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16;
             int bq = b;
-            if (a.dbg & 4) { bq = 0; col = ((long long)a.halo + (t0 & 1023) + wn * 128 + r) * 16 + 8 * h; }   // measurement: every tile stores into the first 1024 columns (L2-resident)
+            if (a.dbg & 4) { bq = 0; col = ((long long)a.halo + (t0 & 1023) + wn * 128 + r) * 16; }   // measurement: every tile stores into the first 1024 columns (L2-resident)
             char* zb = a.z.base + (long long)bq * a.z.ustride + col;
             const bool keep = a.sg.base != nullptr;            // training: the sigmoid is kept for the backward pass (tanh = z / sigmoid)
             char* sb = keep ? a.sg.base + (long long)bq * a.sg.ustride + col : zb;
 #pragma unroll
             for (int j = 0; j < MT / 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long long o = (long long)((sl.row0 + wm * 16 * MT + 32 * j + 8 * i) >> 3) * ld * 16;
+                for (int i = 0; i < 4; i += 2) {       // row groups in pairs: 16-byte stores (store8)
+                    const long long o = (long long)(((sl.row0 + wm * 16 * MT + 32 * j + 8 * i) >> 3) + h) * ld * 16;
 #pragma unroll
                     for (int n = 0; n < 4; ++n) {
-                        float vt[4], vs[4], vz[4];
+                        float vsa[4], vza[4], vsb[4], vzb[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            vt[q] = h_tanh(acc[2 * j][n][4 * i + q] * osc + bvec[2 * j][i][q]);
-                            vs[q] = h_sigmoid(acc[2 * j + 1][n][4 * i + q] * osc + bvec[2 * j + 1][i][q]);
-                            vz[q] = vt[q] * vs[q];
+                            const float ta = h_tanh(acc[2 * j][n][4 * i + q] * osc + bvec[2 * j][i][q]);
+                            vsa[q] = h_sigmoid(acc[2 * j + 1][n][4 * i + q] * osc + bvec[2 * j + 1][i][q]);
+                            vza[q] = ta * vsa[q];
+                            const float tb = h_tanh(acc[2 * j][n][4 * i + 4 + q] * osc + bvec[2 * j][i + 1][q]);
+                            vsb[q] = h_sigmoid(acc[2 * j + 1][n][4 * i + 4 + q] * osc + bvec[2 * j + 1][i + 1][q]);
+                            vzb[q] = tb * vsb[q];
                         }
                         const long long on = o + n * 512;
-                        store4<P, BF, false>(zb + on, a.z.pstride, vz, ovf);
-                        if (keep) store4<P, BF, false>(sb + on, a.sg.pstride, vs, ovf);   // wave-uniform; no load is pending
+                        store8<P, BF, false>(zb + on, a.z.pstride, vza, vzb, ovf);
+                        if (keep) store8<P, BF, false>(sb + on, a.sg.pstride, vsa, vsb, ovf);   // wave-uniform; no load is pending
                     }
                 }
+            if constexpr (!BF) {
+                if (ovf && a.flag) atomicOr(a.flag, 1u);
+            }
+            return;
+        }
+    } else if constexpr (MT == 2 && EPI == HEPI_DGATE && P == 1) {
+        // one-plane modes: row groups in pairs, 16-byte stores (two planes would need 128 more registers for the pair prefetch: spills)
+        if (full_cols && sl.row0 + ROWS <= a.da.cp) {
+            typedef typename HT<BF>::v4 V4;
+            const long long col = ((long long)a.halo + t0 + wn * 128 + r) * 16;
+            const char* tab = a.z.base + (long long)b * a.z.ustride + col + 8 * h;          // z = tanh * sigmoid (the tanh itself is not stored)
+            const char* sgb = a.sg.base + (long long)b * a.sg.ustride + col + 8 * h;
+            char* dab = a.da.base + (long long)b * a.da.ustride + col;                     // (stores: whole units, see store8)
+            char* dgb = a.dg.base + (long long)b * a.dg.ustride + col;
+            constexpr int NG = MT * 4;                         // row groups of 8 channels per wave, taken in pairs
+            V4 rt[2][2][4][P], rs[2][2][4][P];                 // raw z / sigmoid of a PAIR of row groups, one pair ahead of the stores
+            auto fetch = [&](int g, V4 (&ft)[2][4][P], V4 (&fs)[2][4][P]) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const long long o = (long long)((sl.row0 + rowbase + 8 * (g + e)) >> 3) * ld * 16;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int p = 0; p < P; ++p) {
+                            ft[e][n][p] = *reinterpret_cast<const V4*>(tab + o + n * 512 + p * a.z.pstride);
+                            fs[e][n][p] = *reinterpret_cast<const V4*>(sgb + o + n * 512 + p * a.sg.pstride);
+                        }
+                }
+            };
+            fetch(0, rt[0], rs[0]);
+#pragma unroll
+            for (int g = 0; g < NG; g += 2) {
+                const int cur = (g >> 1) & 1;
+                if (g + 2 < NG) fetch(g + 2, rt[cur ^ 1], rs[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int m = g >> 2, i = g & 3;               // groups g, g + 1 = registers 4 i .., 4 i + 4 .. of row tile m
+                const long long o = (long long)(((sl.row0 + rowbase + 8 * g) >> 3) + h) * ld * 16;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    float va[2][4], vg[2][4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float z_ = (float)rt[cur][e][n][0][q], s_ = (float)rs[cur][e][n][0][q];
+                            if constexpr (P == 2) { z_ += (float)rt[cur][e][n][1][q]; s_ += (float)rs[cur][e][n][1][q]; }
+                            const float dz = acc[m][n][4 * (i + e) + q] * osc;
+                            dgate(dz, z_, s_, va[e][q], vg[e][q]);
+                        }
+                    store8<P, BF>(dab + o + n * 512, a.da.pstride, va[0], va[1], ovf);
+                    store8<P, BF>(dgb + o + n * 512, a.dg.pstride, vg[0], vg[1], ovf);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (!BF) {
                 if (ovf && a.flag) atomicOr(a.flag, 1u);
             }

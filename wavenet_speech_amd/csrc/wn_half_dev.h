@@ -66,6 +66,39 @@ __device__ __forceinline__ void store4(char* p, long long pstride, const float (
     }
 }
 
+// The same for TWO row groups (i, i + 1) of one time step at once: this lane holds channels 4h .. 4h + 3 of both (h = lane >> 5).
+// After v_permlane32_swap of the packed halves, lanes 0-31 own the whole 16-byte unit of group i and lanes 32-63 that of group
+// i + 1: ONE 16-byte store per plane instead of two 8-byte ones (the epilogues are store-issue bursts: cdna guide T21).
+// `p` = this lane's unit: group (i + h) of its column, WITHOUT the 8 h byte offset store4 takes.
+template <int P, bool BF, bool CHK = true>
+__device__ __forceinline__ void store8(char* p, long long pstride, const float (&va)[4], const float (&vb)[4], unsigned& ovf) {
+    typedef typename HT<BF>::t T;
+    typedef typename HT<BF>::v4 V4;
+    V4 ha, hb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ha[q] = (T)va[q]; hb[q] = (T)vb[q]; }
+    if constexpr (P == 2) { ha = pin(ha); hb = pin(hb); }
+    if constexpr (!BF && CHK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ovf |= (!(__builtin_fabsf(va[q]) <= 65504.0f) || !(__builtin_fabsf(vb[q]) <= 65504.0f)) ? 1u : 0u;
+    }
+    {
+        const u32x2 ua = __builtin_bit_cast(u32x2, ha), ub = __builtin_bit_cast(u32x2, hb);
+        const auto sx = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+        *reinterpret_cast<u32x4*>(p) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+    }
+    if constexpr (P == 2) {
+        V4 la, lb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { la[q] = (T)(va[q] - (float)ha[q]); lb[q] = (T)(vb[q] - (float)hb[q]); }
+        const u32x2 ua = __builtin_bit_cast(u32x2, la), ub = __builtin_bit_cast(u32x2, lb);
+        const auto sx = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+        *reinterpret_cast<u32x4*>(p + pstride) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+    }
+}
+
 template <int P, bool BF>
 __device__ __forceinline__ void load4(const char* p, long long pstride, float (&v)[4]) {
     typedef typename HT<BF>::v4 V4;
