@@ -13,11 +13,16 @@
  * Conventions
  *  - plain C: raw DEVICE pointers, ints, a stream handle (hipStream_t passed as void*).  No torch types.
  *  - the library never allocates or frees device memory and keeps no device state: every buffer
- *    (activations, packed weights, saved tensors, workspaces) is owned by the caller.
+ *    (activations, packed weights, saved tensors, workspaces) is owned by the caller.  Host-side state it does keep:
+ *    the measurement hooks' event lists (wn_prof_*, off by default, process-wide behind a mutex) and the text of the last
+ *    HIP error per thread (wn_last_hip_error).
  *  - every function only enqueues work on `stream` and returns 0 or a negative wn_status code;
  *    no exceptions cross the ABI.  wn_strerror() gives the text.
  *  - re-entrant; one process per GPU for data parallelism.
- *  - dtype: fp32 storage, fp32 arithmetic (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+ *  - dtype: the wn_block_* / wn_conv_* / wn_skipsum_* entry points are fp32 storage and fp32 arithmetic
+ *    (v_mfma_f32_32x32x2_f32, exact fp32 fma chains); the wn_h* entry points further down are the half-precision-MFMA modes
+ *    (wn_precision: f16x3 = two fp16 planes per operand and three products, f16, bf16; fp32 accumulation, their own
+ *    "half series" layout).
  *
  * Padded series layout (all activation tensors -- "series" of B utterances x C channels x L steps)
  *    float buf[B][Cp][ld],  Cp = wn_round_up(C, 8),  ld = halo + wn_round_up(L,128) + halo
@@ -239,7 +244,8 @@ int wn_ctc_loss(const float* logits, const long long* labels, const long long* l
  * Half-precision-MFMA modes of the same path (opt-in; the entry points above stay exact fp32).
  *
  *   WN_F16X3  every operand is split into two fp16 planes (hi, lo); each product is hi*hi + hi*lo + lo*hi on
- *             v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-equivalent results at 3/16 of the fp32 MFMA cost.
+ *             v_mfma_f32_32x32x16_f16 with fp32 accumulation: 22-bit operands at 3/16 of the fp32 MFMA cost (within 1e-4 of the
+ *             fp32 path on conditioned models; 3-4x further from fp64 than fp32 on the reference's ill-conditioned random init).
  *   WN_F16 / WN_BF16   one plane of fp16 / bf16 storage, one MFMA per product, fp32 accumulation
  *             (the dtypes BASELINE.json configs[4] / configs[1] name).
  *

@@ -2,7 +2,7 @@
 Host side of the half-precision-MFMA modes of the residual stack ("f16x3", "f16", "bf16"): the same
 torch.autograd.Function shape as functional._ResidualStackFn, driving the wn_h* entry points of the C ABI.
 
-    f16x3  operands split into two fp16 planes, three MFMAs per product, fp32 accumulate: fp32-equivalent results
+    f16x3  operands split into two fp16 planes, three MFMAs per product, fp32 accumulate: 22-bit operands, within 1e-4 of the fp32 path on conditioned models
            (same 1e-4 parity bar as the fp32 path) at 3/16 of the fp32 MFMA cost
     f16 / bf16   plain half storage + MFMA, fp32 accumulate (BASELINE configs[4] / configs[1]); their error is the
            storage format's (measured in tests/test_gpu_half.py), far from 1e-4 through 30 blocks

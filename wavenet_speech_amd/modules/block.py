@@ -104,7 +104,7 @@ PRECISIONS = ("f32", "f16x3", "f16", "bf16")
 def pointwise_precision(precision):
     """the mode of a model's convolutions OUTSIDE its residual stack (entry conv, feature layer, 1x1 convs of the output
     stacks).  In the plain half modes they follow the stack (wn_hconv_*).  In "f16x3" they stay exact fp32: the mode's claim is
-    fp32-equivalent results at the 1e-4 bar on the reference's own outputs and gradients, and those include LeakyReLU kinks --
+    results at the fp32 path's 1e-4 bar on the reference's own outputs and gradients (conditioned models), and those include LeakyReLU kinks --
     a 1e-7 perturbation of the stack's INPUT flips the sign of an element of skips_sum that happens to lie within 1e-6 of
     zero (measured: 1 of 19 200 in the smoke model, 2e-1 max-norm error in that one gradient element, a golden fixture fails),
     while the stack's own f16x3 rounding does not reach its input.  The half convs themselves are exact to 7e-7 in f16x3
@@ -126,7 +126,7 @@ def head_precision(precision):
 def set_precision(module, precision):
     """Select the arithmetic of the residual stacks of `module` (a WaveNet / RawCTCNet / WaveNetClassifier or anything
     containing them): "f32" exact fp32 MFMA (default); "f16x3" fp16 MFMA with every operand split into a high and a low
-    half (3 products, fp32 accumulate: fp32-equivalent results at 3/16 of the fp32 MFMA cost); "f16" / "bf16" plain
+    half (3 products, fp32 accumulate: 22-bit operands, within 1e-4 of the fp32 path on conditioned models, at 3/16 of the fp32 MFMA cost); "f16" / "bf16" plain
     half-precision storage and MFMA with fp32 accumulation (BASELINE configs[4] / configs[1]).  The 1x1 convs of the output
     stacks follow the stack in every half mode, the entry conv / feature layer in the plain half modes only; see
     pointwise_precision and head_precision."""
