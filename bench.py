@@ -249,6 +249,11 @@ SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm
              "hdgate": r"hgemm_kernel<\d+, \d+, \w+, 2>|hgemm8_kernel<\d+, \w+, 2,",
              "hf32": r"hgemm_kernel<\d+, \d+, \w+, 3>|hgemm8_kernel<\d+, \w+, 3,",
              "hwgrad": r"hwgrad_kernel<", "hfused": r"hfused_fwd_kernel<"}
+# half block kernels: channel vectors (of C elements) moved per (utterance, time step) by one launch when every operand is read
+# once and every result written once: (without skip path, extra with skip path).  hfused (training): x in; z, tanh|sigmoid, r out.
+# dz: dr, tanh|sigmoid in [+ skip gradient]; da|dg out.  dx: da|dg, dr in; dx out.  hgate: x in; tanh|sigmoid out.
+# (hwgrad launches cover several blocks each and are MFMA-bound wherever they lead: not listed.)
+ALG_CHANNELS = {"hfused": (5, 0), "hdgate": (5, 1), "hstore": (4, 0), "hgate": (3, 0)}
 SYMBOL_NOTE = {"linear": "EPI_LINEAR: res, dx, skips_sum, conv launches", "gate": "EPI_GATE", "dgate": "EPI_DGATE: dz", "wgrad": "",
                "hstore": "HEPI_STORE: res, dx", "hgate": "HEPI_GATE", "hdgate": "HEPI_DGATE: dz", "hf32": "HEPI_F32: skips_sum, convs",
                "hwgrad": "", "hfused": "gate -> z -> res [+ skip] in one launch"}
@@ -613,6 +618,20 @@ def main():
                                        "frac": round(nprod * v[2] / (v[0] * 1e-3) / 1e12 / peak, 4),
                                        "share_of_step": round(v[0] / args.steps / (step_s * 1e3), 4)}
                                       for k, v in by_symbol.items() if k != dom}}
+        # which roof binds this kernel?  Its own algorithmic HBM bytes per launch (every operand read once, every result
+        # written once: ALG_CHANNELS[symbol] channel vectors of C elements per (utterance, time step))
+        # over the same HIP-event duration, against 8 TB/s -- next to the MFMA fraction above.  The larger fraction is the bound.
+        if half and dom in ALG_CHANNELS:
+            has_skip = 1 if args.model == "wavenet" else 0
+            alg_b = (ALG_CHANNELS[dom][0] + has_skip * ALG_CHANNELS[dom][1]) * C * esz * float(B) * L_eff
+            gbs = alg_b / (ms / n * 1e-3) / 1e9
+            roofline["mfma"] = {"achieved": roofline["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roofline["frac"]}
+            roofline["hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "algorithmic_bytes_per_launch": alg_b,
+                               "measured_traffic_gbs": round(traffic / (ms / n * 1e-3) / 1e9, 1) if traffic else None}
+            if gbs / PEAK_HBM_GBS > ach / peak:
+                roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / PEAK_HBM_GBS, 4)})
         if traffic is not None:
             # algorithmic bytes per (utterance, time step, block) = 8 C s for the whole fwd+bwd of a block
             roofline["traffic_vs_block_algorithmic_bytes"] = round(traffic / (8.0 * C * esz * float(B) * L_eff), 3)

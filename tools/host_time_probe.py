@@ -28,7 +28,7 @@ else:
     x = torch.randn(B, C, L, device=dev)
     cot = torch.randn(B, C, L, device=dev)
 W.set_precision(net, prec)
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+opt = torch.optim.Adam(net.parameters(), lr=0.0, fused=True)   # lr 0: the random-init model must not drift into fp16 overflow while probing
 from wavenet_speech_amd.parallel import FlatGradAllReduce
 sync = FlatGradAllReduce(net.parameters())
 
@@ -58,3 +58,21 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+
+# which tensors do the small fill / copy kernels touch?  (torch.profiler with shapes, 3 steps; backward runs on the autograd
+# thread, so Python stacks are not available there -- shapes identify the call sites well enough)
+if os.environ.get("WN_PROBE_FILLS", "1") != "0":
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    from collections import Counter
+    sites = Counter()
+    for ev in prof.events():
+        if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add_", "aten::mul_", "aten::cat", "aten::add", "aten::mul",
+                       "aten::sum", "aten::bmm", "aten::matmul"):
+            own = [s for s in (ev.stack or []) if "wavenet_speech_amd" in s or "host_time_probe" in s]
+            sites[(ev.name, str(ev.input_shapes)[:60], own[0][-70:] if own else "-")] += 1
+    for (name, shp, site), n in sites.most_common(45):
+        print("%6.1f per step  %-12s %-60s %s" % (n / 3.0, name, shp, site))
