@@ -139,8 +139,8 @@ struct HFusedPlan {
 };
 
 bool fused_forward_enabled() {
-    static const bool off = getenv("WN_FUSED_FWD") && atoi(getenv("WN_FUSED_FWD")) == 0;
-    return !off;
+    const char* e = getenv("WN_FUSED_FWD");      // read per call: the parity tests compare both forms in one process
+    return !(e && atoi(e) == 0);
 }
 
 struct HBlockPlan {
@@ -889,8 +889,8 @@ struct HWPlan {
 };
 
 bool composite_wgrad(int ci, int co, int ms) {
-    static const bool off = getenv("WN_HWGRAD_COMPOSITE") && atoi(getenv("WN_HWGRAD_COMPOSITE")) == 0;
-    return !off && cp32(ci) <= 128 && cp32(co) <= 128 && cp32(ms) <= 128;
+    const char* e = getenv("WN_HWGRAD_COMPOSITE");   // read per call (tests compare both forms)
+    return !(e && atoi(e) == 0) && cp32(ci) <= 128 && cp32(co) <= 128 && cp32(ms) <= 128;
 }
 
 std::vector<HPairSpec> hblock_pairs(const wn_block_shape* s, const int* off, const void* x, const void* z, const void* da,
