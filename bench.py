@@ -250,10 +250,11 @@ SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm
              "hf32": r"hgemm_kernel<\d+, \d+, \w+, 3>|hgemm8_kernel<\d+, \w+, 3,",
              "hwgrad": r"hwgrad_kernel<", "hfused": r"hfused_fwd_kernel<"}
 # half block kernels: channel vectors (of C elements) moved per (utterance, time step) by one launch when every operand is read
-# once and every result written once: (without skip path, extra with skip path).  hfused (training): x in; z, tanh|sigmoid, r out.
-# dz: dr, tanh|sigmoid in [+ skip gradient]; da|dg out.  dx: da|dg, dr in; dx out.  hgate: x in; tanh|sigmoid out.
-# (hwgrad launches cover several blocks each and are MFMA-bound wherever they lead: not listed.)
-ALG_CHANNELS = {"hfused": (5, 0), "hdgate": (5, 1), "hstore": (4, 0), "hgate": (3, 0)}
+# once and every result written once: (always, extra when the model has a skip path -- every reference model has one).
+# hfused (training): x in; z, sigmoid(g), r out.  dz: dr, sigmoid(g), z in [+ the gradient of skips_sum]; da|dg out.
+# dx: da|dg, dr in; dx out.  hgate: x in; sigmoid(g), z out.
+# hwgrad: x, da|dg, z, dr in (the weight gradients themselves are negligible), per block.
+ALG_CHANNELS = {"hfused": (4, 0), "hdgate": (5, 1), "hstore": (4, 0), "hgate": (3, 0), "hwgrad": (5, 0)}
 SYMBOL_NOTE = {"linear": "EPI_LINEAR: res, dx, skips_sum, conv launches", "gate": "EPI_GATE", "dgate": "EPI_DGATE: dz", "wgrad": "",
                "hstore": "HEPI_STORE: res, dx", "hgate": "HEPI_GATE", "hdgate": "HEPI_DGATE: dz", "hf32": "HEPI_F32: skips_sum, convs",
                "hwgrad": "", "hfused": "gate -> z -> res [+ skip] in one launch"}
@@ -622,8 +623,12 @@ def main():
         # written once: ALG_CHANNELS[symbol] channel vectors of C elements per (utterance, time step))
         # over the same HIP-event duration, against 8 TB/s -- next to the MFMA fraction above.  The larger fraction is the bound.
         if half and dom in ALG_CHANNELS:
-            has_skip = 1 if args.model == "wavenet" else 0
+            has_skip = 1
             alg_b = (ALG_CHANNELS[dom][0] + has_skip * ALG_CHANNELS[dom][1]) * C * esz * float(B) * L_eff
+            if dom == "hwgrad":
+                # its launches cover several blocks each (and the convs around the stack, whose bytes are NOT counted here: a
+                # lower bound): the blocks' operand bytes of a step, spread over the launches of a step
+                alg_b = alg_b * nblk / (n / float(args.steps))
             gbs = alg_b / (ms / n * 1e-3) / 1e9
             roofline["mfma"] = {"achieved": roofline["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roofline["frac"]}
             roofline["hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),

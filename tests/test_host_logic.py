@@ -119,3 +119,25 @@ def test_series_pool_is_capped_and_lru():
     assert pool.free_bytes <= pool.cap_bytes
     assert pool.take(("cpu", 1, 8, 100, 0, 128)) is None          # the oldest shapes were dropped
     assert pool.take(("cpu", 1, 8, 129, 0, 128)) is not None      # the newest survive
+
+
+def test_pack_cache_keeps_a_bounded_number_of_shapes():
+    """frozen inference over utterances of many lengths must not keep one packed copy of every block per length."""
+    from wavenet_speech_amd.functional import PackCache
+
+    class _Layout(object):
+        def __init__(self, n):
+            self.n = n
+
+        def key(self):
+            return ("layout", self.n)
+
+    c = PackCache()
+    for n in range(10):                      # ten utterance lengths, three blocks each
+        for l in range(3):
+            c.put(l, _Layout(n), 1, ("packed", n, l))
+    assert len(c.packed) == 3 * PackCache.MAX_SHAPES
+    assert c.get(0, _Layout(0), 1) is None and c.get(2, _Layout(9), 1) == ("packed", 9, 2)
+    c.get(0, _Layout(6), 1)                  # touching the oldest surviving shape protects it from the next eviction
+    c.put(0, _Layout(10), 1, "x")
+    assert c.get(0, _Layout(6), 1) is not None and c.get(0, _Layout(7), 1) is None

@@ -289,16 +289,34 @@ class PackCache(object):
         if key != self.key:
             self.key = key
             self.packed = {}
+            self.__dict__["_shapes"] = []
+
+    MAX_SHAPES = 4        # distinct (series layout, batch) shapes whose packed weights are kept (variable-length inference would
+                          # otherwise keep one packed copy of every block per utterance length: ADVICE r02)
 
     def get(self, l, layout, batch):
-        t = self.packed.get((l, layout.key(), batch))
+        shape = (layout.key(), batch)
+        t = self.packed.get((l,) + shape)
         if t is not None:
             self.hits += 1
+            self._touch(shape)
         return t
 
     def put(self, l, layout, batch, t):
-        self.packed[(l, layout.key(), batch)] = t
+        shape = (layout.key(), batch)
+        self._touch(shape)
+        self.packed[(l,) + shape] = t
         return t
+
+    def _touch(self, shape):
+        order = self.__dict__.setdefault("_shapes", [])
+        if shape in order:
+            order.remove(shape)
+        order.append(shape)
+        while len(order) > self.MAX_SHAPES:
+            old = order.pop(0)                       # least recently used shape: drop its packed weights
+            for k in [k for k in self.packed if k[1:] == old]:
+                del self.packed[k]
 
 
 def residual_stack(x, specs, flat_params, precision="f32", pack_cache=None, head=None, front=None, pool=1):
