@@ -98,6 +98,7 @@ def test_fused_forward_equals_two_launch_form_and_oracle(precision, case, monkey
     HF.profile_enable(False)
     launched = {k: v[1] for k, v in HF.profile_read().items() if v[1]}
     assert "hfused_fwd_kernel" not in launched and launched.get("hgemm_kernel<gate>", 0) == len(dil), launched
+    assert not any(k.startswith("hcol_kernel") for k in launched), launched     # (the two-launch form also runs dz / dx on hgemm_kernel)
 
     # oracle (fp32, CPU)
     xr = x.clone().requires_grad_(True)
@@ -181,3 +182,60 @@ def test_block_group_weight_gradients_equal_per_block_form(precision, monkeypatc
         scale = max(float(g.abs().max()), 1e-30)
         assert float((g - g_single[2][k]).abs().max()) <= 2e-6 * scale, k
         assert float((g - g_plain[2][k]).abs().max()) <= 2e-6 * scale, k
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [(128, (1, 2, 512), 128, False, 3, 1030), (128, (4, 1), 128, True, 2, 257), (96, (2, 8), 96, True, 2, 517),
+                                  (64, (1, 16), 64, False, 1, 1000), (24, (1, 2), 24, True, 2, 77), (8, (1,), 8, True, 1, 1),
+                                  (40, (4, 1), 40, False, 5, 33), (128, (1, 2), 96, True, 2, 300)])
+def test_column_owner_dz_dx_equal_the_tiled_gemms(precision, case, monkeypatch):
+    """hcol_kernel (dz and dx of blocks of <= 128 channels as column-owner streaming kernels, wn_col.hip) against hgemm_kernel on
+    the same packed weights (WN_COL_BWD=0): the same products in the same k order with fp32 accumulation; the dgate epilogue
+    uses a reciprocal where the tiled kernel divides, so da / dg agree to rounding of the storage format."""
+    c, dil, out_dim, causal, B, L = case
+    net = _Stack(c, dil, out_dim, causal, seed=21).to(DEV)
+    net.stack_state.precision = precision
+    other = copy.deepcopy(net)
+    torch.manual_seed(4)
+    x = torch.randn(B, c, L, device=DEV)
+    cot = torch.randn(B, out_dim, L, device=DEV)
+    monkeypatch.setenv("WN_COL_BWD", "1")
+    HF.profile_reset()
+    HF.profile_enable(True)
+    s1, dx1, g1 = _eval(net, x, cot)
+    HF.profile_enable(False)
+    launched = {k: v[1] for k, v in HF.profile_read().items() if v[1]}
+    same_width = (out_dim + 31) // 32 == (c + 31) // 32
+    if same_width:
+        assert launched.get("hcol_kernel<dz,dgate>", 0) == len(dil) and launched.get("hcol_kernel<dx>", 0) == len(dil) - 1, launched
+    else:
+        assert not any(k.startswith("hcol_kernel") for k in launched), launched       # a narrower skip path keeps the tiled kernels
+    monkeypatch.setenv("WN_COL_BWD", "0")
+    HF.profile_reset()
+    HF.profile_enable(True)
+    s0, dx0, g0 = _eval(other, x, cot)
+    HF.profile_enable(False)
+    launched = {k: v[1] for k, v in HF.profile_read().items() if v[1]}
+    assert not any(k.startswith("hcol_kernel") for k in launched) and launched.get("hgemm_kernel<dz,dgate>", 0) == len(dil), launched
+    assert torch.equal(s1, s0)                                   # the forward is the same code
+    errs = {"dx": O.rel_err(dx1.cpu(), dx0.cpu())}
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            errs[k] = O.rel_err(g1[k].cpu(), g0[k].cpu())
+    w = max(errs, key=errs.get)
+    print("%s %s: column-owner vs tiled: dx %.2e, worst %s %.2e" % (precision, case, errs["dx"], w, errs[w]))
+    assert errs[w] <= PAIR[precision], (w, errs[w])
+
+
+def test_column_owner_kernels_on_flattened_columns_of_many_short_utterances():
+    """units are 32 consecutive valid columns of the flattened (utterance, time) space: utterances shorter than a unit share one"""
+    net = _Stack(32, (1, 2), 32, True, seed=3).to(DEV)
+    net.stack_state.precision = "bf16"
+    torch.manual_seed(8)
+    x = torch.randn(37, 32, 5, device=DEV)                       # 185 columns: 6 units, each spanning 6-7 utterances
+    cot = torch.randn(37, 32, 5, device=DEV)
+    full = _eval(net, x, cot)
+    for b in (0, 17, 36):
+        one = _eval(net, x[b:b + 1].contiguous(), cot[b:b + 1].contiguous())
+        assert torch.equal(one[0][0], full[0][b]) and torch.equal(one[1][0], full[1][b]), b

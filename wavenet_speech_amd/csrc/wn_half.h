@@ -184,6 +184,25 @@ struct HFusedArgs {
     unsigned long long* stamps; // measurement only (WN_FUSED_STAMPS): 8 s_memtime stamps per workgroup
 };
 hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st);
+
+// ---- column-owner backward-data GEMMs (wn_col.hip): dz and dx of a block of <= 128 channels, one-plane modes --------------------
+constexpr int kColMaxK = 40;                        // 16-channel k-steps: dx at 128 channels = (2 taps x 2 + 1) x 8
+struct HColArgs {
+    const char* wstream;            // the slab's packed weights: `nks` k-step images of 4 KiB ([k-half][128 rows][16 B])
+    const char* kbase[kColMaxK];    // k-step kk: lane (utterance b, time t, k-half h) reads its B fragment at
+    long long kustride[kColMaxK];   //     kbase[kk] + b * kustride[kk] + ((long long)h * ld + halo + t) * 16   (tap offset and channel group inside kbase)
+    HDst z, sg, da, dg;             // HEPI_DGATE: in (tanh = z / sigmoid), out
+    HDst dst;                       // HEPI_STORE
+    unsigned* flag;
+    char* dump;                     // 1 KiB that masked store lanes write to
+    float oscale;
+    int nks, nt;                    // k-steps; row tiles of 32 output channels
+    int B, L, ld, halo, nunit;      // nunit = ceil(B * L / 32) units of 32 consecutive valid columns
+    int nwg;                        // workgroups of four units (set by the launcher)
+    int dbg;
+};
+static_assert(sizeof(HColArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+hipError_t launch_hcol(int prec, int epi, const HColArgs& a, hipStream_t st);
 static_assert(sizeof(HWgradArgs) <= 4096 && sizeof(HGemmArgs) <= 4096 && sizeof(HFusedArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);

@@ -143,9 +143,16 @@ bool fused_forward_enabled() {
     return !(e && atoi(e) == 0);
 }
 
+// column-owner dz / dx (wn_col.hip): the blocks the fused forward takes, when the skip path is as wide as the block
+bool col_backward_enabled() {
+    const char* e = getenv("WN_COL_BWD");        // read per call: the parity tests compare both forms in one process
+    return !(e && atoi(e) == 0);
+}
+
 struct HBlockPlan {
     HPlan fa, fr, fs, ka, kb;
     HFusedPlan fu;
+    bool col = false;               // dz and dx run as hcol_kernel (KA / KB keep hgemm_kernel's 128-row packing for it)
     size_t off_fa = 0, off_fr = 0, off_fs = 0, off_ka = 0, off_kb = 0, total = 0;
 };
 
@@ -153,6 +160,9 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     HBlockPlan p;
     const int P = hp_planes(prec);
     const int Ci = s->in_channels, Co = s->out_channels, Ms = s->skip_rows, k = s->kernel_width;
+    const bool fused_ok = fused_forward_enabled() && P == 1 && k == 2 && cp32(Ci) == cp32(Co) && cp32(Co) <= 128 && Ms <= 128 &&
+                          k * cp32(Ci) / 16 <= kFMaxGateK;
+    p.col = fused_ok && col_backward_enabled() && cp32(Ms) == cp32(Co);
     {   // FA: [a ; g] interleaved in 32-channel tile pairs; K = k taps of x
         HPlan& g = p.fa;
         g.init(2 * Co, P, false, s->length, true, true);
@@ -178,7 +188,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KA: dz rows (z channels) contract [dskip ; dr]
         HPlan& g = p.ka;
-        g.init(Co, P, false, s->length, false, true);
+        g.init(Co, P, false, s->length, false, !p.col);
         g.nseg = 2;
         g.seg_nks[0] = cp32(Ms) / 16;
         g.seg_nks[1] = cp32(Co) / 16;
@@ -186,7 +196,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     }
     {   // KB: dx rows (input channels) contract [da_0; dg_0; ...; dr]
         HPlan& g = p.kb;
-        g.init(Ci, P, false, s->length, false, true);
+        g.init(Ci, P, false, s->length, false, !p.col);
         g.nseg = 2 * k + 1;
         for (int j = 0; j < 2 * k + 1; ++j) g.seg_nks[j] = cp32(Co) / 16;
         for (int r0 = 0; r0 < Ci; r0 += g.rows) g.add_slab(2 * k + 1, r0);
@@ -196,7 +206,7 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
         f.nci16 = cp32(Ci) / 16; f.nzt = cp32(Co) / 32; f.nkg = k * f.nci16; f.ngh = (f.nzt + 1) / 2;
         f.st_gate = f.nkg / 2; f.st_res = f.nzt + f.nci16 / 2; f.st_skip = f.nzt;
         // (two taps and equally padded channel counts: the kernel is instantiated per z-tile count with every loop bound a constant)
-        f.on = fused_forward_enabled() && P == 1 && k == 2 && cp32(Ci) == cp32(Co) && cp32(Co) <= 128 && Ms <= 128 && f.nkg <= kFMaxGateK;
+        f.on = fused_ok;
     }
     // a block that runs the fused forward packs no separate gate / res / skip weights
     p.off_fa = 0;
@@ -265,7 +275,7 @@ inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
 
 // profiling classes shared with wn_api.hip (same table, same order)
 enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
-       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA };
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX };
 
 }  // namespace
 
@@ -545,6 +555,25 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
 }
 
 namespace {
+// an hgemm argument block (one slab of <= 128 rows, segments set) as the column-owner kernel's
+void col_args(HColArgs& c, const HGemmArgs& a, const HBlockPlan& bp, const void* packed, const wn_block_shape* s) {
+    std::memset(&c, 0, sizeof(c));
+    c.wstream = a.wpacked + a.slab[0].woff;
+    int kk = 0;
+    for (int i = 0; i < a.slab[0].nseg; ++i)
+        for (int j = 0; j < a.seg[i].nks && kk < kColMaxK; ++j, ++kk) {
+            c.kbase[kk] = a.seg[i].base + ((long long)a.seg[i].off + 2LL * j * s->ld) * 16;
+            c.kustride[kk] = a.seg[i].ustride;
+        }
+    c.nks = kk;
+    c.nt = cp32(s->out_channels) / 32;
+    c.flag = a.flag;
+    c.dump = (char*)packed + bp.fu.off_bias + align256(4 * kFRows * sizeof(float));
+    c.oscale = a.oscale;
+    c.B = s->batch; c.L = s->length; c.ld = s->ld; c.halo = s->halo;
+    c.nunit = (int)(((long long)s->batch * s->length + 31) / 32);
+}
+
 int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
                               const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                               const float* dyn_inv_scale, const void* dx_mask, float dx_slope, unsigned* overflow_flag,
@@ -571,8 +600,16 @@ int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void
         a.da = dst_of(vda); a.dg = dst_of(vdg);
         a.gate_rows = Co;
         a.flag = overflow_flag;
-        wn::ProfScopeShared prof(KC_HDZ, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
-        WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_DGATE, a, st), "hgemm<dz>");
+        if (bp.col) {
+            HColArgs c;
+            col_args(c, a, bp, packed, s);
+            c.z = a.z; c.sg = a.sg; c.da = a.da; c.dg = a.dg;
+            wn::ProfScopeShared prof(KC_HCOL_DZ, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
+            WN_HIP(launch_hcol(precision, HEPI_DGATE, c, st), "hcol<dz>");
+        } else {
+            wn::ProfScopeShared prof(KC_HDZ, 2.0 * Co * (double)(Ms + (dr ? Co : 0)) * BL, st);
+            WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_DGATE, a, st), "hgemm<dz>");
+        }
     }
     if (dx || dx_dense) {
         const HPlan& g = bp.kb;
@@ -585,13 +622,19 @@ int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void
         if (dr) set_hseg(a, 2 * k, view(dr, Co, s->ld, P), 0, g.seg_nks[2 * k]);
         for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = 2 * k + (dr ? 1 : 0);
         a.flag = overflow_flag;
-        wn::ProfScopeShared prof(KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
+        const bool col_dx = dx && !dx_mask && bp.col;
+        wn::ProfScopeShared prof(col_dx ? KC_HCOL_DX : KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
         if (dx && dx_mask) {
             // the block's input was leaky(.) of a front-end conv kept in the series: dx is masked by its stored activation
             a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
             a.z = dst_of(view(dx_mask, Ci, s->ld, P));
             a.oscale2 = 1.0f; a.leaky = dx_slope;
             WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_LEAKY, a, st), "hgemm<dx masked>");
+        } else if (col_dx) {
+            HColArgs c;
+            col_args(c, a, bp, packed, s);
+            c.dst = dst_of(view(dx, Ci, s->ld, P));
+            WN_HIP(launch_hcol(precision, HEPI_STORE, c, st), "hcol<dx>");
         } else if (dx) {
             a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
             WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_STORE, a, st), "hgemm<dx>");
