@@ -239,3 +239,47 @@ def test_column_owner_kernels_on_flattened_columns_of_many_short_utterances():
     for b in (0, 17, 36):
         one = _eval(net, x[b:b + 1].contiguous(), cot[b:b + 1].contiguous())
         assert torch.equal(one[0][0], full[0][b]) and torch.equal(one[1][0], full[1][b]), b
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("model", ["wavenet", "rawctc"])
+def test_series_convs_and_masked_dx_column_owner_equal_tiled(precision, model, monkeypatch):
+    """the 1x1 convs of the output block / feature layer (LeakyReLU fused forward, its derivative fused backward) and the first
+    block's masked dx as hcol_kernel against hgemm_kernel<HEPI_LEAKY> (WN_COL_BWD=0): the forward is the same arithmetic in the same
+    order -> bitwise; the gradients differ only through dz's reciprocal (rounding of the storage format)."""
+    import wavenet_speech_amd as W
+    from wavenet_speech_amd.modules.raw_ctcnet import RawCTCNet
+    from wavenet_speech_amd.modules.wavenet import WaveNet
+    torch.manual_seed(6)
+    if model == "wavenet":
+        net = WaveNet(64, 2, [(64, 64, 2, d) for d in (1, 2, 4)], 64, softmax=False).to(DEV)
+        x = torch.randn(2, 64, 333, device=DEV)
+        cot = torch.randn(2, 64, 333, device=DEV)
+    else:
+        net = RawCTCNet(96, 3, 5, [(96, 96, 2, d) for d in (1, 2, 8)], 96, softmax=False, causal=False).to(DEV)
+        x = torch.randn(3, 1, 500, device=DEV)
+        cot = torch.randn(3, 5, 502, device=DEV)
+    W.set_precision(net, precision)
+    other = copy.deepcopy(net)
+
+    def run(n):
+        for p in n.parameters():
+            p.grad = None
+        HF.profile_reset()
+        HF.profile_enable(True)
+        y = n(x)
+        (y * cot).sum().backward()
+        HF.profile_enable(False)
+        return y.detach(), {k: (None if p.grad is None else p.grad.clone()) for k, p in n.named_parameters()}, \
+            {k: v[1] for k, v in HF.profile_read().items() if v[1]}
+
+    monkeypatch.setenv("WN_COL_BWD", "1")
+    y1, g1, k1 = run(net)
+    monkeypatch.setenv("WN_COL_BWD", "0")
+    y0, g0, k0 = run(other)
+    assert any(k.startswith("hcol_kernel") for k in k1) and not any(k.startswith("hcol_kernel") for k in k0), (k1, k0)
+    assert torch.equal(y1, y0)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            assert O.rel_err(g1[k].cpu(), g0[k].cpu()) <= PAIR[precision], k

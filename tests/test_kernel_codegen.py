@@ -19,7 +19,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 
 # per-file flags of csrc/Makefile (FLAGS_<file>): the assembly checked here must be the product's
-EXTRA_FLAGS = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"],
+               "wn_col_conv.hip": ["-fno-slp-vectorize"]}
 
 
 def _asm(src, tmp_path):
@@ -38,7 +39,7 @@ def test_ring_kernels_keep_their_prefetch_in_flight(tmp_path):
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 66, r.stdout
 
 
-@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_embed.hip",
+@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_col_conv.hip", "wn_embed.hip",
                                  "wn_nll.hip", "wn_pack.hip"])
 def test_no_kernel_uses_scratch(src, tmp_path):
     text = open(_asm(src, tmp_path)).read()
@@ -62,33 +63,36 @@ def test_column_owner_kernels_wait_for_exactly_their_stage(tmp_path):
         x = (nks + 4 * (m + 1) - KCRES + 1) // 2 if nks + 4 * (m + 1) - KCRES + 1 >= 0 else 0
         return min(max(x, 0), nks // 2)
 
-    def visible_at(X, nks, nt, dgate):
+    def epi_loads(epi):                      # per row tile: dgate reads z and sigmoid (8), the leaky epilogues bias or mask (4)
+        return {2: 8, 100: 4, 101: 4}.get(epi, 0)
+
+    def visible_at(X, nks, nt, epi):
         n = sum(1 for j in range(KCRES, nks) if X > 0 and frag_at(j) == X)
-        if dgate:
-            n += sum(8 for m in range(nt) if epi_at(m, nks) == X)
+        n += sum(epi_loads(epi) for m in range(nt) if epi_at(m, nks) == X)
         return n
 
-    def expected(nks, nt, dgate):
+    def expected(nks, nt, epi):
         nst = nks // 2
         out = []
         for S in range(nst):
             ahead = min(nst - 1 - S, KCD - 2)
-            out.append(KCPW * ahead + sum(visible_at(X, nks, nt, dgate) for X in range(max(0, S - KCD + 2), S + 1)))
+            out.append(KCPW * ahead + sum(visible_at(X, nks, nt, epi) for X in range(max(0, S - KCD + 2), S + 1)))
         return out
 
-    text = open(_asm("wn_col.hip", tmp_path)).read()
     seen = 0
-    for m in re.finditer(r"^(_ZN2wn11hcol_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
-        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        bf, nt, nks, epi = re.search(r"hcol_kernel<(\w+), (\d+), (\d+), (\d+)>", name).groups()
-        lines = [l.strip() for l in m.group(2).splitlines()]
-        bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
-        waits = []
-        for b in bars[1:]:                       # (the first barrier closes the prologue: its wait is the visible vmcnt(0))
-            w = [l for l in lines[max(0, b - 3):b] if re.match(r"s_waitcnt vmcnt\(\d+\)$", l)]
-            assert w, (name, "no counted wait in front of a K-loop barrier")
-            waits.append(int(re.match(r"s_waitcnt vmcnt\((\d+)\)", w[-1]).group(1)))
-        assert waits == expected(int(nks), int(nt), int(epi) == 2), (name, waits, expected(int(nks), int(nt), int(epi) == 2))
-        assert len(bars) == int(nks) // 2 + 1, name
-        seen += 1
-    assert seen == 32, seen                      # 8 dz + 8 dx shapes x (bf16, f16)
+    for src in ("wn_col.hip", "wn_col_conv.hip"):
+        text = open(_asm(src, tmp_path)).read()
+        for m in re.finditer(r"^(_ZN2wn11hcol_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            bf, nt, nks, epi = re.search(r"hcol_kernel<(\w+), (\d+), (\d+), (\d+)>", name).groups()
+            lines = [l.strip() for l in m.group(2).splitlines()]
+            bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+            waits = []
+            for b in bars[1:]:                   # (the first barrier closes the prologue: its wait is the visible vmcnt(0))
+                w = [l for l in lines[max(0, b - 3):b] if re.match(r"s_waitcnt vmcnt\(\d+\)$", l)]
+                assert w, (name, "no counted wait in front of a K-loop barrier")
+                waits.append(int(re.match(r"s_waitcnt vmcnt\((\d+)\)", w[-1]).group(1)))
+            assert waits == expected(int(nks), int(nt), int(epi)), (name, waits, expected(int(nks), int(nt), int(epi)))
+            assert len(bars) == int(nks) // 2 + 1, name
+            seen += 1
+    assert seen == 48 + 64, seen                 # (8 dz + 8 dx + 8 masked dx shapes) + (16 conv shapes x forward / backward), x (bf16, f16)

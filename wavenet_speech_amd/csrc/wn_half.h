@@ -192,17 +192,20 @@ struct HColArgs {
     const char* kbase[kColMaxK];    // k-step kk: lane (utterance b, time t, k-half h) reads its B fragment at
     long long kustride[kColMaxK];   //     kbase[kk] + b * kustride[kk] + ((long long)h * ld + halo + t) * 16   (tap offset and channel group inside kbase)
     HDst z, sg, da, dg;             // HEPI_DGATE: in (tanh = z / sigmoid), out
-    HDst dst;                       // HEPI_STORE
+    HDst dst;                       // HEPI_STORE / leaky epilogues
+    HDst mask;                      // leaky backward: the activation whose sign bit is the mask
+    const float* bias;              // leaky forward: fp32 [128], already multiplied by the output scale (zeros past the valid rows)
     unsigned* flag;
     char* dump;                     // 1 KiB that masked store lanes write to
-    float oscale;
+    float oscale, oscale2, leaky;
     int nks, nt;                    // k-steps; row tiles of 32 output channels
     int B, L, ld, halo, nunit;      // nunit = ceil(B * L / 32) units of 32 consecutive valid columns
     int nwg;                        // workgroups of four units (set by the launcher)
     int dbg;
 };
 static_assert(sizeof(HColArgs) <= 4096, "kernel arguments are limited to 4 KiB");
-hipError_t launch_hcol(int prec, int epi, const HColArgs& a, hipStream_t st);
+hipError_t launch_hcol(int prec, int epi, const HColArgs& a, hipStream_t st);        // dz (HEPI_DGATE), dx (HEPI_STORE; HEPI_LEAKY: masked)
+hipError_t launch_hcol_conv(int prec, bool backward, const HColArgs& a, hipStream_t st);   // 1x1 convs in the series with LeakyReLU epilogues
 static_assert(sizeof(HWgradArgs) <= 4096 && sizeof(HGemmArgs) <= 4096 && sizeof(HFusedArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);

@@ -556,24 +556,27 @@ int wn_hblock_forward(const wn_block_shape* s, int precision, const void* packed
 
 namespace {
 // an hgemm argument block (one slab of <= 128 rows, segments set) as the column-owner kernel's
-void col_args(HColArgs& c, const HGemmArgs& a, const HBlockPlan& bp, const void* packed, const wn_block_shape* s) {
+void col_args_common(HColArgs& c, const HGemmArgs& a, int out_rows, char* dump, int B, int L, int ld, int halo) {
     std::memset(&c, 0, sizeof(c));
     c.wstream = a.wpacked + a.slab[0].woff;
     int kk = 0;
     for (int i = 0; i < a.slab[0].nseg; ++i)
         for (int j = 0; j < a.seg[i].nks && kk < kColMaxK; ++j, ++kk) {
-            c.kbase[kk] = a.seg[i].base + ((long long)a.seg[i].off + 2LL * j * s->ld) * 16;
+            c.kbase[kk] = a.seg[i].base + ((long long)a.seg[i].off + 2LL * j * ld) * 16;
             c.kustride[kk] = a.seg[i].ustride;
         }
     c.nks = kk;
-    c.nt = cp32(s->out_channels) / 32;
+    c.nt = cp32(out_rows) / 32;
     c.flag = a.flag;
-    c.dump = (char*)packed + bp.fu.off_bias + align256(4 * kFRows * sizeof(float));
+    c.dump = dump;
     c.oscale = a.oscale;
-    c.B = s->batch; c.L = s->length; c.ld = s->ld; c.halo = s->halo;
-    c.nunit = (int)(((long long)s->batch * s->length + 31) / 32);
+    c.B = B; c.L = L; c.ld = ld; c.halo = halo;
+    c.nunit = (int)(((long long)B * L + 31) / 32);
 }
-
+void col_args(HColArgs& c, const HGemmArgs& a, const HBlockPlan& bp, const void* packed, const wn_block_shape* s) {
+    col_args_common(c, a, s->out_channels, (char*)packed + bp.fu.off_bias + align256(4 * kFRows * sizeof(float)), s->batch, s->length,
+                    s->ld, s->halo);
+}
 int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
                               const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                               const float* dyn_inv_scale, const void* dx_mask, float dx_slope, unsigned* overflow_flag,
@@ -622,9 +625,16 @@ int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void
         if (dr) set_hseg(a, 2 * k, view(dr, Co, s->ld, P), 0, g.seg_nks[2 * k]);
         for (int i = 0; i < a.nslab; ++i) a.slab[i].nseg = 2 * k + (dr ? 1 : 0);
         a.flag = overflow_flag;
-        const bool col_dx = dx && !dx_mask && bp.col;
+        const bool col_dx = dx && bp.col;
         wn::ProfScopeShared prof(col_dx ? KC_HCOL_DX : KC_HDX, 2.0 * Ci * (double)(2 * k * Co + (dr ? Co : 0)) * BL, st);
-        if (dx && dx_mask) {
+        if (dx && dx_mask && bp.col) {
+            HColArgs c;
+            col_args(c, a, bp, packed, s);
+            c.dst = dst_of(view(dx, Ci, s->ld, P));
+            c.mask = dst_of(view(dx_mask, Ci, s->ld, P));
+            c.oscale2 = 1.0f; c.leaky = dx_slope;
+            WN_HIP(launch_hcol(precision, HEPI_LEAKY, c, st), "hcol<dx masked>");
+        } else if (dx && dx_mask) {
             // the block's input was leaky(.) of a front-end conv kept in the series: dx is masked by its stored activation
             a.dst[0] = dst_of(view(dx, Ci, s->ld, P));
             a.z = dst_of(view(dx_mask, Ci, s->ld, P));
@@ -1159,10 +1169,14 @@ int check_hconv(const wn_conv_shape* s, int prec, int* off) {
     for (int j = 0; j < s->kernel_width; ++j) mx = std::max(mx, std::abs(off[j]));
     return check_hlayout(s->batch, s->length, s->ld, s->halo, mx);
 }
-struct HConvPlan { HPlan f, kb; size_t off_f = 0, off_kb = 0, total = 0; };
+struct HConvPlan {
+    HPlan f, kb; size_t off_f = 0, off_kb = 0, off_dump = 0, total = 0;
+    bool col = false;    // the series-to-series forms of a 1x1 conv of <= 128 channels run as hcol_kernel (wn_col_conv.hip)
+};
 HConvPlan plan_hconv(const wn_conv_shape* s, int prec) {
     HConvPlan p;
     const int P = hp_planes(prec), Ci = s->in_channels, Co = s->out_channels, k = s->kernel_width;
+    p.col = col_backward_enabled() && P == 1 && k == 1 && cp32(Ci) <= 128 && cp32(Co) <= 128;
     p.f.init(Co, P);
     p.f.nseg = k;
     for (int j = 0; j < k; ++j) p.f.seg_nks[j] = cp32(Ci) / 16;
@@ -1173,7 +1187,8 @@ HConvPlan plan_hconv(const wn_conv_shape* s, int prec) {
     for (int r0 = 0; r0 < Ci; r0 += p.kb.rows) p.kb.add_slab(k, r0);
     p.off_f = 0;
     p.off_kb = p.f.bytes();
-    p.total = p.off_kb + p.kb.bytes();
+    p.off_dump = p.off_kb + p.kb.bytes();
+    p.total = p.off_dump + 1024;                     // the line that masked store lanes of hcol_kernel write to
     return p;
 }
 }  // namespace
@@ -1272,6 +1287,13 @@ int wn_hconv_forward_series(const wn_conv_shape* s, int precision, const void* p
     a.dst[0] = dst_of(view(y_series, Co, s->ld, P));
     a.oscale2 = out_scale; a.leaky = leaky_slope; a.flag = overflow_flag;
     wn::ProfScopeShared prof(KC_HCONV_FWD, 2.0 * Co * (double)(k * Ci) * (double)s->batch * s->length, st);
+    if (cp.col && cp.f.nslab == 1 && cp.f.MT == 2 && !cp.f.k32) {
+        HColArgs c;
+        col_args_common(c, a, Co, (char*)packed + cp.off_dump, s->batch, s->length, s->ld, s->halo);
+        c.dst = a.dst[0]; c.bias = a.bias; c.oscale2 = out_scale; c.leaky = leaky_slope;
+        WN_HIP(launch_hcol_conv(precision, false, c, st), "hcol<conv series>");
+        return WN_OK;
+    }
     WN_HIP(launch_hgemm(precision, cp.f.kernel(), HEPI_LEAKY, a, st), "hgemm<conv series>");
     return WN_OK;
 }
@@ -1296,6 +1318,13 @@ int wn_hconv_backward_data_series(const wn_conv_shape* s, int precision, const v
     if (act) a.z = dst_of(view(act, Ci, s->ld, P));
     a.oscale2 = 1.0f; a.leaky = act ? leaky_slope : 1.0f; a.flag = overflow_flag;
     wn::ProfScopeShared prof(KC_HCONV_BWD_DATA, 2.0 * Ci * (double)(k * Co) * (double)s->batch * s->length, st);
+    if (cp.col && act && cp.kb.nslab == 1 && cp.kb.MT == 2 && !cp.kb.k32) {
+        HColArgs c;
+        col_args_common(c, a, Ci, (char*)packed + cp.off_dump, s->batch, s->length, s->ld, s->halo);
+        c.dst = a.dst[0]; c.mask = a.z; c.oscale2 = 1.0f; c.leaky = leaky_slope;
+        WN_HIP(launch_hcol_conv(precision, true, c, st), "hcol<conv dx series>");
+        return WN_OK;
+    }
     WN_HIP(launch_hgemm(precision, cp.kb.kernel(), HEPI_LEAKY, a, st), "hgemm<conv dx series>");
     return WN_OK;
 }
