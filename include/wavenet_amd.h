@@ -292,7 +292,10 @@ int wn_hskipsum_forward(const wn_skipsum_shape* s, int precision, const void* pa
                         float* skip_dense, int accumulate, wn_stream_t stream);
 /* dr (nullable), dskip, z, sg (the forward pass's), da, dg: half series (gradients carry the scale s).  The input gradient goes
  * either to the half series dx (scaled by s, the next block's dr) or to dense fp32 dx_dense [B][Ci][L] multiplied by
- * *dyn_inv_scale. */
+ * *dyn_inv_scale.  Blocks that take the fused forward and whose skip path is as wide as the block (<= 128 channels, one-plane
+ * modes) run dz and the series dx as column-owner streaming kernels (hcol_kernel, csrc/wn_col_dev.h: the autograd of the
+ * reference's modules/block.py:65-79 with the activations read straight from the series into registers); same arguments, same
+ * packed weights.  The 1x1 wn_hconv_*_series calls below do likewise. */
 int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
                             const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                             const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream);
