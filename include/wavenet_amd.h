@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define WN_VERSION 201 /* 0.2.1 */
+#define WN_VERSION 300 /* 0.3.0: round-3 entry points (fused forward, block-group weight gradients, pack tables, series convs, front-ends) */
 
 typedef void* wn_stream_t; /* hipStream_t */
 

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     from wavenet_speech_amd import _lib
     lib = _lib.load()
-    assert lib.wn_version() == 201
+    assert lib.wn_version() == 300
     assert lib.wn_strerror(0) == b"ok"
     assert b"workspace" in lib.wn_strerror(-5)
     assert lib.wn_round_up(13, 8) == 16

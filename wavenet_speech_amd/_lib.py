@@ -169,7 +169,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.wn_version() < 201:
+    if lib.wn_version() < 300:
         raise RuntimeError("libwavenet_amd.so too old")
     _lib = lib
     return lib
