@@ -4,8 +4,11 @@ import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "wavenet_speech_amd", "csrc")
 files = sys.argv[1:] or ["wn_gemm.hip", "wn_wgrad.hip", "wn_pack.hip"]
+# per-file flags of csrc/Makefile (FLAGS_<file>): report the product's code
+extra = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"],
+         "wn_col_conv.hip": ["-fno-slp-vectorize"]}
 for f in files:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-c", os.path.join(src, f),
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950"] + extra.get(f, []) + ["-c", os.path.join(src, f),
                           "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     cur = None
     for line in out.splitlines():

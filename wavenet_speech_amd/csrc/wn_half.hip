@@ -253,8 +253,17 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
     int is_ks = 0;                                           // next k-step to issue
     int is_seg = 0, is_left = a.seg[0].nks;
     long long is_pstride = a.seg[0].pstride;
+    // (measurement, dbg & 8: every tile READS its B operand from the first 1024 columns of utterance 0 -- L2-resident: what the
+    // launch would cost if its operands never came from HBM, e.g. the residual product inside a fused forward)
+    // in the diagnostic build `make l2operands` (never loaded by the product path; the extra selects cost two instantiations a spill)
+#ifdef WN_MEASURE_L2_OPERANDS
+    const int b_ld = (a.dbg & 8) ? 0 : b;
+    const long long unit0 = (long long)a.halo + ((a.dbg & 8) ? (t0 & 1023) : t0) + 64 * wave;
+#else
+    const int b_ld = b;
     const long long unit0 = (long long)a.halo + t0 + 64 * wave;   // this wave's first time unit of the tile (+ tap offset)
-    const char* b_src = a.seg[0].base + (long long)b * a.seg[0].ustride + (unit0 + a.seg[0].off) * 16;
+#endif
+    const char* b_src = a.seg[0].base + (long long)b_ld * a.seg[0].ustride + (unit0 + a.seg[0].off) * 16;
     const unsigned lane16 = lane * 16u;
 
     // PW pieces per wave and stage: A_PW of the weight tile, then B_PW of the activation tile (plane, k-group)
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void hgemm_kernel(const HGemm
                 const HSeg ns = a.seg[is_seg];
                 is_left = ns.nks;
                 is_pstride = ns.pstride;
-                b_src = ns.base + (long long)b * ns.ustride + (unit0 + ns.off) * 16;
+                b_src = ns.base + (long long)b_ld * ns.ustride + (unit0 + ns.off) * 16;
             }
         }
     };
@@ -1135,7 +1144,8 @@ hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a_in, hipStr
     if (a_in.nslab <= 0 || a_in.B <= 0 || a_in.L <= 0) return hipSuccess;
     HGemmArgs a = a_in;
     static const int dbg = getenv("WN_HGEMM_DBG") ? atoi(getenv("WN_HGEMM_DBG")) : 0;
-    a.dbg = dbg;
+    static const int dbg_epi = getenv("WN_HGEMM_DBG_EPI") ? atoi(getenv("WN_HGEMM_DBG_EPI")) : -1;   // restrict the knob to one epilogue class
+    a.dbg = (dbg_epi < 0 || dbg_epi == epi) ? dbg : 0;
     if (MT == 10) {  // hgemm8_kernel, four waves on 128 x 256 tiles, two workgroups per CU (one-plane modes)
         if (a.L % 16 != 0 || prec == HP_F16X3) return hipErrorInvalidValue;
         a.tiles_per_row = (a.L + 255) / 256;
