@@ -321,6 +321,22 @@ int wn_hconv_forward_series(const wn_conv_shape* s, int precision, const void* p
 int wn_hconv_backward_data_series(const wn_conv_shape* s, int precision, const void* packed, const void* dy, const void* act,
                                   float leaky_slope, void* dx_series, unsigned* overflow_flag, wn_stream_t stream);
 
+/* dx of `upper` and dz (-> da, dg) of `lower`, the block directly below it in the stack, in ONE launch: dz is pointwise in time
+ * and its dr operand is the dx tile the same wave has just computed, so it goes from the MFMA result registers straight back into
+ * the MFMA (csrc/wn_col2.hip: the autograd of two consecutive `out, skip = block(out)` steps of modules/wavenet.py:98-100).
+ * dx_upper is still written (the lower block's weight gradients read it as their dr).  Only for pairs for which
+ * wn_hblock_backward_pair_is_fused() == 1 (both blocks take the column-owner kernels, equal widths and geometry); otherwise
+ * WN_ERR_UNSUPPORTED and the caller uses wn_hblock_backward_data per block.  dr_upper nullable (the top block of a stack).
+ * wn_hblock_backward_input: the input gradient of a block whose gate gradients exist already (the bottom of such a chain). */
+int wn_hblock_backward_pair_is_fused(const wn_block_shape* upper, const wn_block_shape* lower, int precision);
+int wn_hblock_backward_pair(const wn_block_shape* upper, const void* packed_upper, const wn_block_shape* lower, const void* packed_lower,
+                            int precision, const void* dr_upper, const void* da_upper, const void* dg_upper, const void* dskip,
+                            const void* z_lower, const void* sg_lower, void* dx_upper, void* da_lower, void* dg_lower,
+                            unsigned* overflow_flag, wn_stream_t stream);
+int wn_hblock_backward_input(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* da, const void* dg,
+                             void* dx, float* dx_dense, const float* dyn_inv_scale, const void* x_act, float leaky_slope,
+                             unsigned* overflow_flag, wn_stream_t stream);
+
 /* The first block of a stack whose input x is the ACTIVATED output of a front-end conv kept in the series (x_act = leaky(.) as
  * stored): dx = (input gradient) * leaky'(x_act), written to the half series dx -- wn_hblock_backward_data plus the LeakyReLU
  * backward of the layer in front, in one epilogue. */

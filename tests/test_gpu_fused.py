@@ -184,11 +184,12 @@ def test_block_group_weight_gradients_equal_per_block_form(precision, monkeypatc
         assert float((g - g_plain[2][k]).abs().max()) <= 2e-6 * scale, k
 
 
+@pytest.mark.parametrize("pair", ["1", "0"])
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
-@pytest.mark.parametrize("case", [(128, (1, 2, 512), 128, False, 3, 1030), (128, (4, 1), 128, True, 2, 257), (96, (2, 8), 96, True, 2, 517),
+@pytest.mark.parametrize("case", [(128, (1, 2, 512), 128, False, 3, 1030), (128, (4, 1), 128, True, 2, 257), (96, (2, 8, 1), 96, True, 2, 517),
                                   (64, (1, 16), 64, False, 1, 1000), (24, (1, 2), 24, True, 2, 77), (8, (1,), 8, True, 1, 1),
                                   (40, (4, 1), 40, False, 5, 33), (128, (1, 2), 96, True, 2, 300)])
-def test_column_owner_dz_dx_equal_the_tiled_gemms(precision, case, monkeypatch):
+def test_column_owner_dz_dx_equal_the_tiled_gemms(precision, case, pair, monkeypatch):
     """hcol_kernel (dz and dx of blocks of <= 128 channels as column-owner streaming kernels, wn_col.hip) against hgemm_kernel on
     the same packed weights (WN_COL_BWD=0): the same products in the same k order with fp32 accumulation; the dgate epilogue
     uses a reciprocal where the tiled kernel divides, so da / dg agree to rounding of the storage format."""
@@ -200,14 +201,21 @@ def test_column_owner_dz_dx_equal_the_tiled_gemms(precision, case, monkeypatch):
     x = torch.randn(B, c, L, device=DEV)
     cot = torch.randn(B, out_dim, L, device=DEV)
     monkeypatch.setenv("WN_COL_BWD", "1")
+    monkeypatch.setenv("WN_COL_PAIR", pair)      # 1: dx of a block and dz of the block below it in one launch (hcol2_kernel, wn_col2.hip)
     HF.profile_reset()
     HF.profile_enable(True)
     s1, dx1, g1 = _eval(net, x, cot)
     HF.profile_enable(False)
     launched = {k: v[1] for k, v in HF.profile_read().items() if v[1]}
     same_width = (out_dim + 31) // 32 == (c + 31) // 32
-    if same_width:
-        assert launched.get("hcol_kernel<dz,dgate>", 0) == len(dil) and launched.get("hcol_kernel<dx>", 0) == len(dil) - 1, launched
+    n = len(dil)
+    if same_width and pair == "1" and n > 1:
+        # dz of the top block, n - 1 paired launches, the bottom block's dense dx (the stack's input is dense here) on hgemm_kernel
+        assert launched.get("hcol_kernel<dz,dgate>", 0) == 1 and launched.get("hcol2_kernel<dx+dz>", 0) == n - 1 and \
+            "hcol_kernel<dx>" not in launched and launched.get("hgemm_kernel<dx>", 0) == 1, launched
+    elif same_width:
+        assert launched.get("hcol_kernel<dz,dgate>", 0) == n and launched.get("hcol_kernel<dx>", 0) == n - 1 and \
+            "hcol2_kernel<dx+dz>" not in launched, launched
     else:
         assert not any(k.startswith("hcol_kernel") for k in launched), launched       # a narrower skip path keeps the tiled kernels
     monkeypatch.setenv("WN_COL_BWD", "0")

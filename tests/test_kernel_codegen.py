@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 # per-file flags of csrc/Makefile (FLAGS_<file>): the assembly checked here must be the product's
 EXTRA_FLAGS = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"],
-               "wn_col_conv.hip": ["-fno-slp-vectorize"]}
+               "wn_col_conv.hip": ["-fno-slp-vectorize"], "wn_col2.hip": ["-fno-slp-vectorize"]}
 
 
 def _asm(src, tmp_path):
@@ -39,7 +39,7 @@ def test_ring_kernels_keep_their_prefetch_in_flight(tmp_path):
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 66, r.stdout
 
 
-@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_col_conv.hip", "wn_embed.hip",
+@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_col_conv.hip", "wn_col2.hip", "wn_embed.hip",
                                  "wn_nll.hip", "wn_pack.hip"])
 def test_no_kernel_uses_scratch(src, tmp_path):
     text = open(_asm(src, tmp_path)).read()
@@ -96,3 +96,45 @@ def test_column_owner_kernels_wait_for_exactly_their_stage(tmp_path):
             assert len(bars) == int(nks) // 2 + 1, name
             seen += 1
     assert seen == 48 + 64, seen                 # (8 dz + 8 dx + 8 masked dx shapes) + (16 conv shapes x forward / backward), x (bf16, f16)
+
+
+def test_paired_dx_dz_kernel_waits_for_exactly_its_stage(tmp_path):
+    """hcol2_kernel (wn_col2.hip: dx of a block and dz of the block below it in one launch): the same exact-count discipline, with
+    two products on one stage stream, a fragment stream that continues from dx's operands into dz's dS segment, the dgate inputs
+    scheduled as dS dies, and the dx STORES between the two products counted for the stages whose pieces were issued before them."""
+    KCD, KCRES, KCPW = 6, 16, 2
+
+    def frag_at(j):
+        return 0 if j < KCRES else 2 * ((j - KCRES) // 4 + 1)
+
+    def expected(nt, hasdr):
+        nks1 = (10 if hasdr else 8) * nt
+        nst1, nf, nst = nks1 // 2, nks1 + 2 * nt, nks1 // 2 + 2 * nt
+        epi_at = [min(nst1 + 2 * (m + 1), nst) for m in range(nt)]
+
+        def visible_at(X):
+            return sum(1 for j in range(KCRES, nf) if X > 0 and frag_at(j) == X) + sum(8 for m in range(nt) if epi_at[m] == X)
+
+        out = []
+        for S in range(nst):
+            y = KCPW * min(nst - 1 - S, KCD - 2) + sum(visible_at(X) for X in range(max(0, S - KCD + 2), S + 1))
+            if nst1 <= S <= nst1 + KCD - 2:
+                y += 2 * nt
+            out.append(y)
+        return out
+
+    text = open(_asm("wn_col2.hip", tmp_path)).read()
+    seen = 0
+    for m in re.finditer(r"^(_ZN2wn12hcol2_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        bf, nt, hasdr = re.search(r"hcol2_kernel<(\w+), (\d+), (\w+)>", name).groups()
+        lines = [l.strip() for l in m.group(2).splitlines()]
+        bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+        waits = []
+        for b in bars[1:]:
+            w = [l for l in lines[max(0, b - 3):b] if re.match(r"s_waitcnt vmcnt\(\d+\)$", l)]
+            assert w, (name, "no counted wait in front of a K-loop barrier")
+            waits.append(int(re.match(r"s_waitcnt vmcnt\((\d+)\)", w[-1]).group(1)))
+        assert waits == expected(int(nt), hasdr == "true"), (name, waits, expected(int(nt), hasdr == "true"))
+        seen += 1
+    assert seen == 16, seen

@@ -88,6 +88,11 @@ SIGNATURES = {
     "wn_hblock_pack": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p]),
     "wn_hblock_pack_checked": (c_int, [POINTER(BlockShape), c_int, POINTER(BlockParams), c_void_p, c_void_p, c_void_p]),
     "wn_hblock_forward_is_fused": (c_int, [POINTER(BlockShape), c_int]),
+    "wn_hblock_backward_pair_is_fused": (c_int, [POINTER(BlockShape), POINTER(BlockShape), c_int]),
+    "wn_hblock_backward_pair": (c_int, [POINTER(BlockShape), c_void_p, POINTER(BlockShape), c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wn_hblock_backward_input": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float_p, c_float_p,
+                                         c_void_p, c_float, c_void_p, c_void_p]),
     "wn_hblock_forward": (c_int, [POINTER(BlockShape), c_int, c_void_p, c_void_p, c_void_p, c_float_p, c_int, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
     "wn_hskipsum_packed_bytes": (c_size_t, [POINTER(SkipSumShape), c_int]),

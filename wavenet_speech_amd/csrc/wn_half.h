@@ -204,6 +204,23 @@ struct HColArgs {
     int dbg;
 };
 static_assert(sizeof(HColArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+// dx of a block + dz of the block below it in one launch (wn_col2.hip)
+constexpr int kCol2MaxK = 48;                       // dx's k-steps (<= 40) + the dS segment of dz (<= 8)
+struct HCol2Args {
+    const char* wstream1;           // the upper block's KB slab (dx weights)
+    const char* wstream2;           // the lower block's KAP slab (dz weights, the dx segment in accumulator order)
+    const char* kbase[kCol2MaxK];   // as HColArgs: dx's operands (da, dg per tap [, dr]) then dS
+    long long kustride[kCol2MaxK];
+    HDst dx;                        // out: the upper block's input gradient = the lower block's dr
+    HDst z, sg, da, dg;             // the lower block's saved activations (in) and gate gradients (out)
+    unsigned* flag;
+    char* dump;
+    float oscale1, oscale2;
+    int nt, hasdr;                  // row tiles of 32 channels (the same for both products); the upper block has a dr operand
+    int B, L, ld, halo, nunit, nwg;
+};
+static_assert(sizeof(HCol2Args) <= 4096, "kernel arguments are limited to 4 KiB");
+hipError_t launch_hcol2(int prec, const HCol2Args& a, hipStream_t st);
 hipError_t launch_hcol(int prec, int epi, const HColArgs& a, hipStream_t st);        // dz (HEPI_DGATE), dx (HEPI_STORE; HEPI_LEAKY: masked)
 hipError_t launch_hcol_conv(int prec, bool backward, const HColArgs& a, hipStream_t st);   // 1x1 convs in the series with LeakyReLU epilogues
 static_assert(sizeof(HWgradArgs) <= 4096 && sizeof(HGemmArgs) <= 4096 && sizeof(HFusedArgs) <= 4096, "kernel arguments are limited to 4 KiB");

@@ -153,7 +153,7 @@ struct HBlockPlan {
     HPlan fa, fr, fs, ka, kb;
     HFusedPlan fu;
     bool col = false;               // dz and dx run as hcol_kernel (KA / KB keep hgemm_kernel's 128-row packing for it)
-    size_t off_fa = 0, off_fr = 0, off_fs = 0, off_ka = 0, off_kb = 0, total = 0;
+    size_t off_fa = 0, off_fr = 0, off_fs = 0, off_ka = 0, off_kb = 0, off_kap = 0, total = 0;
 };
 
 HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
@@ -214,7 +214,8 @@ HBlockPlan plan_hblock(const wn_block_shape* s, int prec) {
     p.off_fs = p.off_fr + (p.fu.on ? 0 : p.fr.bytes());
     p.off_ka = p.off_fs + (p.fu.on ? 0 : p.fs.bytes());
     p.off_kb = p.off_ka + p.ka.bytes();
-    p.fu.off_w = p.off_kb + p.kb.bytes();
+    p.off_kap = p.off_kb + p.kb.bytes();             // KA again with the dr segment in accumulator order (wn_col2.hip), col blocks only
+    p.fu.off_w = p.off_kap + (p.col ? p.ka.bytes() : 0);
     p.fu.off_bias = p.fu.off_w + align256((size_t)p.fu.stages() * kFStageBytes);
     p.total = p.fu.off_w + p.fu.bytes();
     return p;
@@ -275,7 +276,7 @@ inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
 
 // profiling classes shared with wn_api.hip (same table, same order)
 enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
-       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX };
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX, KC_HCOL_DXDZ };
 
 }  // namespace
 
@@ -438,6 +439,15 @@ int fill_hblock_jobs(const wn_block_shape* s, int precision, const wn_block_para
         a.bias = nullptr;
         jobs.push_back(a);
     }
+    if (bp.col) {   // KAP: KA with the dr segment's k in accumulator order: the dx tile of the block above is fed back as it stands
+        const HPlan& g = bp.ka;
+        fill_hpack(a, g, packed, bp.off_kap, precision);
+        a.set[0].seg[0] = hsrc(p->w_skip, Co, Ms, 1, Co, WS);
+        a.set[0].seg[1] = hsrc(p->w_res, Co, Co, 1, Co, WS); a.set[0].seg[1].flags = HPACK_PERM;
+        plain_tiles(a, g, Co);
+        a.bias = nullptr;
+        jobs.push_back(a);
+    }
     {   // KB: rows = input channel; cols = output channel
         const HPlan& g = bp.kb;
         fill_hpack(a, g, packed, bp.off_kb, precision);
@@ -580,11 +590,11 @@ void col_args(HColArgs& c, const HGemmArgs& a, const HBlockPlan& bp, const void*
 int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
                               const void* z, const void* sg, void* da, void* dg, void* dx, float* dx_dense,
                               const float* dyn_inv_scale, const void* dx_mask, float dx_slope, unsigned* overflow_flag,
-                              wn_stream_t stream) {
+                              wn_stream_t stream, bool do_dz = true) {
     int off[WN_MAX_TAPS];
     int rc = check_hblock(s, precision, off);
     if (rc != WN_OK) return rc;
-    if (!packed || !dskip || !z || !sg || !da || !dg) return WN_ERR_NULL;
+    if (!packed || !da || !dg || (do_dz && (!dskip || !z || !sg))) return WN_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const HBlockPlan bp = plan_hblock(s, precision);
     const int P = hp_planes(precision);
@@ -592,7 +602,7 @@ int hblock_backward_data_impl(const wn_block_shape* s, int precision, const void
     const double BL = (double)s->batch * s->length;
     const HView vda = view(da, Co, s->ld, P), vdg = view(dg, Co, s->ld, P);
     HGemmArgs a;
-    {   // dz = W_skip^T dskip + W_res^T dr ; da, dg
+    if (do_dz) {   // dz = W_skip^T dskip + W_res^T dr ; da, dg
         const HPlan& g = bp.ka;
         fill_hgemm(a, g, packed, bp.off_ka, s->batch, s->length, s->ld, s->halo);
         a.bias = nullptr;
@@ -662,6 +672,85 @@ int wn_hblock_backward_data(const wn_block_shape* s, int precision, const void* 
                             const float* dyn_inv_scale, unsigned* overflow_flag, wn_stream_t stream) {
     return hblock_backward_data_impl(s, precision, packed, dr, dskip, z, sg, da, dg, dx, dx_dense, dyn_inv_scale, nullptr, 1.0f,
                                      overflow_flag, stream);
+}
+
+// the input gradient alone, from gate gradients that exist already (computed by wn_hblock_backward_pair): dx in the series,
+// masked by the activation in front of the stack (x_act), or dense
+int wn_hblock_backward_input(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* da, const void* dg,
+                             void* dx, float* dx_dense, const float* dyn_inv_scale, const void* x_act, float leaky_slope,
+                             unsigned* overflow_flag, wn_stream_t stream) {
+    if (!dx && !dx_dense) return WN_ERR_NULL;
+    if (x_act && !dx) return WN_ERR_NULL;
+    return hblock_backward_data_impl(s, precision, packed, dr, nullptr, nullptr, nullptr, const_cast<void*>(da), const_cast<void*>(dg), dx,
+                                     dx_dense, dyn_inv_scale, x_act, leaky_slope, overflow_flag, stream, false);
+}
+
+// ---- dx of `upper` and dz of `lower` (the block below it in the stack) in one launch ---------------------------------------------
+namespace {
+bool pair_fusable(const wn_block_shape* u, const wn_block_shape* l, int precision, const HBlockPlan& pu, const HBlockPlan& pl) {
+    const char* e = getenv("WN_COL_PAIR");       // read per call (tests compare both forms)
+    return !(e && atoi(e) == 0) && pu.col && pl.col && cp32(u->in_channels) == cp32(l->out_channels) && u->in_channels == l->out_channels &&
+           u->batch == l->batch && u->length == l->length && u->ld == l->ld && u->halo == l->halo && u->skip_rows == l->skip_rows &&
+           pu.kb.nslab == 1 && pl.ka.nslab == 1 && !pu.kb.k32 && !pl.ka.k32 && hp_planes(precision) == 1;
+}
+}  // namespace
+
+int wn_hblock_backward_pair_is_fused(const wn_block_shape* upper, const wn_block_shape* lower, int precision) {
+    int off[WN_MAX_TAPS];
+    if (check_hblock(upper, precision, off) != WN_OK || check_hblock(lower, precision, off) != WN_OK) return 0;
+    return pair_fusable(upper, lower, precision, plan_hblock(upper, precision), plan_hblock(lower, precision)) ? 1 : 0;
+}
+
+int wn_hblock_backward_pair(const wn_block_shape* upper, const void* packed_upper, const wn_block_shape* lower, const void* packed_lower,
+                            int precision, const void* dr_upper, const void* da_upper, const void* dg_upper, const void* dskip,
+                            const void* z_lower, const void* sg_lower, void* dx_upper, void* da_lower, void* dg_lower,
+                            unsigned* overflow_flag, wn_stream_t stream) {
+    int offu[WN_MAX_TAPS], offl[WN_MAX_TAPS];
+    int rc = check_hblock(upper, precision, offu);
+    if (rc != WN_OK) return rc;
+    rc = check_hblock(lower, precision, offl);
+    if (rc != WN_OK) return rc;
+    if (!packed_upper || !packed_lower || !da_upper || !dg_upper || !dskip || !z_lower || !sg_lower || !dx_upper || !da_lower || !dg_lower)
+        return WN_ERR_NULL;
+    const HBlockPlan pu = plan_hblock(upper, precision), pl = plan_hblock(lower, precision);
+    if (!pair_fusable(upper, lower, precision, pu, pl)) return WN_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 1, k = upper->kernel_width;
+    const int Ciu = upper->in_channels, Cou = upper->out_channels, Col = lower->out_channels, Ms = lower->skip_rows;
+    const int ld = upper->ld;
+    HCol2Args c;
+    std::memset(&c, 0, sizeof(c));
+    c.wstream1 = (const char*)packed_upper + pu.off_kb + pu.kb.slab_woff[0];
+    c.wstream2 = (const char*)packed_lower + pl.off_kap + pl.ka.slab_woff[0];
+    int kk = 0;
+    auto add_seg = [&](const HView& v, int off, int nks) {
+        for (int j = 0; j < nks && kk < kCol2MaxK; ++j, ++kk) {
+            c.kbase[kk] = v.base + ((long long)off + 2LL * j * ld) * 16;
+            c.kustride[kk] = v.ustride;
+        }
+    };
+    const HView vda = view(da_upper, Cou, ld, P), vdg = view(dg_upper, Cou, ld, P);
+    for (int j = 0; j < k; ++j) {
+        add_seg(vda, -offu[j], pu.kb.seg_nks[2 * j]);
+        add_seg(vdg, -offu[j], pu.kb.seg_nks[2 * j + 1]);
+    }
+    if (dr_upper) add_seg(view(dr_upper, Cou, ld, P), 0, pu.kb.seg_nks[2 * k]);
+    add_seg(view(dskip, Ms, ld, P), 0, pl.ka.seg_nks[0]);
+    c.nt = cp32(Ciu) / 32;
+    c.hasdr = dr_upper ? 1 : 0;
+    if (kk != (c.hasdr ? 10 : 8) * c.nt + 2 * c.nt) return WN_ERR_UNSUPPORTED;
+    c.dx = dst_of(view(dx_upper, Ciu, ld, P));
+    c.z = dst_of(view(z_lower, Col, ld, P)); c.sg = dst_of(view(sg_lower, Col, ld, P));
+    c.da = dst_of(view(da_lower, Col, ld, P)); c.dg = dst_of(view(dg_lower, Col, ld, P));
+    c.flag = overflow_flag;
+    c.dump = (char*)packed_upper + pu.fu.off_bias + align256(4 * kFRows * sizeof(float));
+    c.oscale1 = c.oscale2 = 1.0f / kWeightScale;
+    c.B = upper->batch; c.L = upper->length; c.ld = ld; c.halo = upper->halo;
+    c.nunit = (int)(((long long)upper->batch * upper->length + 31) / 32);
+    const double BL = (double)upper->batch * upper->length;
+    wn::ProfScopeShared prof(KC_HCOL_DXDZ, (2.0 * Ciu * (double)(2 * k * Cou + (dr_upper ? Cou : 0)) + 2.0 * Col * (double)(Ms + Col)) * BL, st);
+    WN_HIP(launch_hcol2(precision, c, st), "hcol2<dx+dz>");
+    return WN_OK;
 }
 
 int wn_hblock_backward_data_masked(const wn_block_shape* s, int precision, const void* packed, const void* dr, const void* dskip,
@@ -768,7 +857,7 @@ int wn_hskipsum_forward_series(const wn_skipsum_shape* s, int precision, const v
 // every step: the folded skip weights) are stored as offsets from that range's base, which the launch supplies.
 namespace {
 constexpr int kMaxDynamic = 3;
-int stack_jobs_upper_bound(int nblocks) { return 5 * nblocks + cdiv(nblocks, WN_MAX_STACK_GROUP); }   // (a fused-forward block also has 5: gate, res, skip, dz, dx)
+int stack_jobs_upper_bound(int nblocks) { return 6 * nblocks + cdiv(nblocks, WN_MAX_STACK_GROUP); }   // (a fused-forward block has up to 6: gate, res, skip, dz, dz for the paired launch, dx)
 
 void encode_dynamic(const float*& ptr, int& flags, const wn_mem_range* dyn, int ndyn) {
     if (!ptr) return;

@@ -432,16 +432,43 @@ class _HalfStackFn(torch.autograd.Function):
                                                        _p(dyn_inv), _p(ws), ws_bytes, _stream()), "wn_hblocks_backward_weights")
             del pending[:]
 
+        # dz is pointwise in time and its dr is the dx of the block above: where two consecutive blocks both take the column-owner
+        # kernels, dx of the upper and dz of the lower run as ONE launch (wn_hblock_backward_pair): the chain is then
+        # dz(top), [dx(l) + dz(l - 1)] ..., dx(bottom) -- n + 1 launches instead of 2 n.
+        gates = None          # (da, dg) of the block about to be processed, if the pair launch above it has produced them
         for l in range(len(specs) - 1, -1, -1):
             spec = specs[l]
             x, sg, z, packed, shape = ctx.saved[l]
-            da, dg = _hlease(mode, B, spec.co, layout, dev), _hlease(mode, B, spec.co, layout, dev)
+            have_dz = gates is not None
+            da, dg = gates if have_dz else (_hlease(mode, B, spec.co, layout, dev), _hlease(mode, B, spec.co, layout, dev))
+            gates = None
             dx = dxd = None
             if l > 0 or ctx.front is not None:
                 dx = _hlease(mode, B, spec.ci, layout, dev)
             elif ctx.needs_input_grad[0]:
                 dxd = dx0 = torch.empty(B, spec.ci, layout.length, dtype=torch.float32, device=dev)
-            if l == 0 and ctx.front is not None:
+            paired = l > 0 and lib.wn_hblock_backward_pair_is_fused(ctypes.byref(shape), ctypes.byref(ctx.saved[l - 1][4]), mode.code) == 1
+            if paired and not have_dz:
+                # the top of a chain: its own dz first (dz only: no dx destination)
+                _lib.check(lib.wn_hblock_backward_data(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
+                                                       _p(da), _p(dg), None, None, _p(dyn_inv), _p(flag), _stream()),
+                           "wn_hblock_backward_data")
+                have_dz = True
+            if paired:
+                _xl, sgl, zl, packedl, shapel = ctx.saved[l - 1]
+                dal, dgl = _hlease(mode, B, specs[l - 1].co, layout, dev), _hlease(mode, B, specs[l - 1].co, layout, dev)
+                _lib.check(lib.wn_hblock_backward_pair(ctypes.byref(shape), _p(packed), ctypes.byref(shapel), _p(packedl), mode.code,
+                                                       _p(dr), _p(da), _p(dg), _p(dS), _p(zl), _p(sgl), _p(dx), _p(dal), _p(dgl),
+                                                       _p(flag), _stream()), "wn_hblock_backward_pair")
+                gates = (dal, dgl)
+            elif have_dz:
+                # the bottom of a chain: the input gradient alone (series, masked by the feature layer's LeakyReLU, or dense)
+                masked = l == 0 and ctx.front is not None
+                _lib.check(lib.wn_hblock_backward_input(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(da), _p(dg), _p(dx), _p(dxd),
+                                                        _p(dyn_inv), _p(x) if masked else None,
+                                                        ctypes.c_float(ctx.front[0][1] if masked else 1.0), _p(flag), _stream()),
+                           "wn_hblock_backward_input")
+            elif l == 0 and ctx.front is not None:
                 # the stack's input is leaky(feature conv): its LeakyReLU backward rides in this block's dx epilogue (x = the stored activation)
                 _lib.check(lib.wn_hblock_backward_data_masked(ctypes.byref(shape), mode.code, _p(packed), _p(dr), _p(dS), _p(z), _p(sg),
                                                               _p(da), _p(dg), _p(dx), _p(x), ctypes.c_float(ctx.front[0][1]), _p(flag),
