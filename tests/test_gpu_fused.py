@@ -188,7 +188,7 @@ def test_block_group_weight_gradients_equal_per_block_form(precision, monkeypatc
 @pytest.mark.parametrize("precision", ["bf16", "f16"])
 @pytest.mark.parametrize("case", [(128, (1, 2, 512), 128, False, 3, 1030), (128, (4, 1), 128, True, 2, 257), (96, (2, 8, 1), 96, True, 2, 517),
                                   (64, (1, 16), 64, False, 1, 1000), (24, (1, 2), 24, True, 2, 77), (8, (1,), 8, True, 1, 1),
-                                  (40, (4, 1), 40, False, 5, 33), (128, (1, 2), 96, True, 2, 300)])
+                                  (40, (4, 1), 40, False, 5, 33), (128, (1, 2), 96, True, 2, 300), (120, (2, 1, 4), 100, True, 2, 130)])
 def test_column_owner_dz_dx_equal_the_tiled_gemms(precision, case, pair, monkeypatch):
     """hcol_kernel (dz and dx of blocks of <= 128 channels as column-owner streaming kernels, wn_col.hip) against hgemm_kernel on
     the same packed weights (WN_COL_BWD=0): the same products in the same k order with fp32 accumulation; the dgate epilogue
