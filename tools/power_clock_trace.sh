@@ -1,9 +1,12 @@
 #!/bin/bash
 # Samples GPU power and shader clock (rocm-smi) every 0.5 s while bench.py runs; prints min/median/max.
 # Usage (GPU box): bash tools/power_clock_trace.sh
+# Usage: power_clock_trace.sh [out file] [bench.py arguments...]   (default: the headline configuration, 40 steps)
 OUT=${1:-gpurun_out/power_clock.txt}
+shift || true
+ARGS=${@:---steps 40 --warmup 2}
 mkdir -p $(dirname $OUT)
-python3 bench.py --steps 40 --warmup 2 > gpurun_out/bench_power.json 2> gpurun_out/bench_power.err &
+python3 bench.py $ARGS > gpurun_out/bench_power.json 2> gpurun_out/bench_power.err &
 BP=$!
 : > $OUT
 while kill -0 $BP 2>/dev/null; do
