@@ -240,7 +240,7 @@ SYMBOL_OF = {
     "hgemm_kernel<gate>": "hgate", "hgemm_kernel<res>": "hstore", "hgemm_kernel<dz,dgate>": "hdgate",
     "hgemm_kernel<dx>": "hstore", "hgemm_kernel<skips_sum>": "hf32", "hgemm_kernel<conv_fwd>": "hf32",
     "hgemm_kernel<conv_bwd_data>": "hf32", "hwgrad_kernel": "hwgrad", "hfused_fwd_kernel": "hfused",
-    "hcol_kernel<dz,dgate>": "hcoldz", "hcol_kernel<dx>": "hcoldx", "hcol2_kernel<dx+dz>": "hcol2",
+    "hcol_kernel<dz,dgate>": "hcoldz", "hcol_kernel<dx>": "hcoldx", "hcol2_kernel<dx+dz>": "hcol2", "hcol_kernel<skips_sum>": "hcolskip",
 }
 # class -> regex on the demangled kernel name.  Template arguments: series_gemm_kernel<MT, NT, EPI, PFB, WPS>,
 # hgemm_kernel<MT, P, BF, EPI>, hgemm8_kernel<P, BF, EPI, NT, WR>, hfused_fwd_kernel<BF, NZT, MODE>, hcol_kernel<BF, NT, NKS, EPI>, hcol2_kernel<BF, NT, HASDR>
@@ -250,7 +250,7 @@ SYMBOL_RE = {"linear": r"series_gemm_kernel<\d+, \d+, 0,", "gate": r"series_gemm
              "hdgate": r"hgemm_kernel<\d+, \d+, \w+, 2>|hgemm8_kernel<\d+, \w+, 2,",
              "hf32": r"hgemm_kernel<\d+, \d+, \w+, 3>|hgemm8_kernel<\d+, \w+, 3,",
              "hwgrad": r"hwgrad_kernel<", "hfused": r"hfused_fwd_kernel<",
-             "hcoldz": r"hcol_kernel<\w+, \d+, \d+, 2>", "hcoldx": r"hcol_kernel<\w+, \d+, \d+, 0>", "hcol2": r"hcol2_kernel<"}
+             "hcoldz": r"hcol_kernel<\w+, \d+, \d+, 2>", "hcoldx": r"hcol_kernel<\w+, \d+, \d+, 0>", "hcol2": r"hcol2_kernel<", "hcolskip": r"hcol_kernel<\w+, \d+, \d{2,3}, 100>"}
 # half block kernels: channel vectors (of C elements) moved per (utterance, time step) by one launch when every operand is read
 # once and every result written once: (always, extra when the model has a skip path -- every reference model has one).
 # hfused (training): x in; z, sigmoid(g), r out.  dz: dr, sigmoid(g), z in [+ the gradient of skips_sum]; da|dg out.
@@ -262,7 +262,7 @@ SYMBOL_NOTE = {"linear": "EPI_LINEAR: res, dx, skips_sum, conv launches", "gate"
                "hstore": "HEPI_STORE: res, dx", "hgate": "HEPI_GATE", "hdgate": "HEPI_DGATE: dz", "hf32": "HEPI_F32: skips_sum, convs",
                "hwgrad": "", "hfused": "gate -> z -> res [+ skip] in one launch",
                "hcoldz": "dz + dgate, column-owner streaming form", "hcoldx": "dx, column-owner streaming form",
-               "hcol2": "dx of a block + dz of the block below it in one launch"}
+               "hcol2": "dx of a block + dz of the block below it in one launch", "hcolskip": "skips_sum -> leaky series, column-owner form"}
 
 
 def profile_dir(args):

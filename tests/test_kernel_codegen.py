@@ -20,7 +20,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 # per-file flags of csrc/Makefile (FLAGS_<file>): the assembly checked here must be the product's
 EXTRA_FLAGS = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"],
-               "wn_col_conv.hip": ["-fno-slp-vectorize"], "wn_col2.hip": ["-fno-slp-vectorize"]}
+               "wn_col_conv.hip": ["-fno-slp-vectorize"], "wn_col2.hip": ["-fno-slp-vectorize"], "wn_col_skip.hip": ["-fno-slp-vectorize"]}
 
 
 def _asm(src, tmp_path):
@@ -39,7 +39,7 @@ def test_ring_kernels_keep_their_prefetch_in_flight(tmp_path):
     assert r.stdout.count("\nok ") + r.stdout.startswith("ok ") >= 66, r.stdout
 
 
-@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_col_conv.hip", "wn_col2.hip", "wn_embed.hip",
+@pytest.mark.parametrize("src", ["wn_gemm.hip", "wn_wgrad.hip", "wn_half.hip", "wn_half_wgrad.hip", "wn_fused.hip", "wn_col.hip", "wn_col_conv.hip", "wn_col_skip.hip", "wn_col2.hip", "wn_embed.hip",
                                  "wn_nll.hip", "wn_pack.hip"])
 def test_no_kernel_uses_scratch(src, tmp_path):
     text = open(_asm(src, tmp_path)).read()
@@ -80,7 +80,7 @@ def test_column_owner_kernels_wait_for_exactly_their_stage(tmp_path):
         return out
 
     seen = 0
-    for src in ("wn_col.hip", "wn_col_conv.hip"):
+    for src in ("wn_col.hip", "wn_col_conv.hip", "wn_col_skip.hip"):
         text = open(_asm(src, tmp_path)).read()
         for m in re.finditer(r"^(_ZN2wn11hcol_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
@@ -95,7 +95,8 @@ def test_column_owner_kernels_wait_for_exactly_their_stage(tmp_path):
             assert waits == expected(int(nks), int(nt), int(epi)), (name, waits, expected(int(nks), int(nt), int(epi)))
             assert len(bars) == int(nks) // 2 + 1, name
             seen += 1
-    assert seen == 48 + 64, seen                 # (8 dz + 8 dx + 8 masked dx shapes) + (16 conv shapes x forward / backward), x (bf16, f16)
+    # (8 dz + 8 dx + 8 masked dx shapes) + (16 conv shapes x forward / backward) + (skips_sum of 1..16 blocks at 64 / 128 channels), x (bf16, f16)
+    assert seen == 48 + 64 + 64, seen
 
 
 def test_paired_dx_dz_kernel_waits_for_exactly_its_stage(tmp_path):

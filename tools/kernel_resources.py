@@ -6,7 +6,7 @@ src = os.path.join(root, "wavenet_speech_amd", "csrc")
 files = sys.argv[1:] or ["wn_gemm.hip", "wn_wgrad.hip", "wn_pack.hip"]
 # per-file flags of csrc/Makefile (FLAGS_<file>): report the product's code
 extra = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp-vectorize"], "wn_col.hip": ["-fno-slp-vectorize"],
-         "wn_col_conv.hip": ["-fno-slp-vectorize"]}
+         "wn_col_conv.hip": ["-fno-slp-vectorize"], "wn_col_skip.hip": ["-fno-slp-vectorize"], "wn_col2.hip": ["-fno-slp-vectorize"]}
 for f in files:
     out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950"] + extra.get(f, []) + ["-c", os.path.join(src, f),
                           "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr

@@ -53,7 +53,7 @@ inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 enum KernelClass {   // the half-precision classes (KC_HLOAD...) are used by wn_half_api.hip, which repeats this order
     KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE,
     KC_CONV_FWD, KC_CONV_BWD_DATA, KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED,
-    KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX, KC_HCOL_DXDZ,
+    KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX, KC_HCOL_DXDZ, KC_HCOL_SKIP,
     KC_COUNT
 };
 const char* const kKernelNames[KC_COUNT] = {
@@ -62,7 +62,7 @@ const char* const kKernelNames[KC_COUNT] = {
     "series_gemm_kernel<conv_bwd_data>", "series_gemm_kernel<skips_sum>", "hload_kernel", "hgemm_kernel<gate>",
     "hgemm_kernel<res>", "hgemm_kernel<dz,dgate>", "hgemm_kernel<dx>", "hgemm_kernel<skips_sum>", "hwgrad_kernel",
     "embed_kernel", "synth_kernel", "ctc_kernel", "hfused_fwd_kernel",
-    "hgemm_kernel<conv_fwd>", "hgemm_kernel<conv_bwd_data>", "hcol_kernel<dz,dgate>", "hcol_kernel<dx>", "hcol2_kernel<dx+dz>"};
+    "hgemm_kernel<conv_fwd>", "hgemm_kernel<conv_bwd_data>", "hcol_kernel<dz,dgate>", "hcol_kernel<dx>", "hcol2_kernel<dx+dz>", "hcol_kernel<skips_sum>"};
 
 struct ProfRec { int kc; hipEvent_t e0, e1; double flops; };
 struct Prof {

@@ -186,7 +186,7 @@ struct HFusedArgs {
 hipError_t launch_hfused_fwd(int prec, const HFusedArgs& a, hipStream_t st);
 
 // ---- column-owner backward-data GEMMs (wn_col.hip): dz and dx of a block of <= 128 channels, one-plane modes --------------------
-constexpr int kColMaxK = 40;                        // 16-channel k-steps: dx at 128 channels = (2 taps x 2 + 1) x 8
+constexpr int kColMaxK = 128;                       // 16-channel k-steps: dx at 128 channels = (2 taps x 2 + 1) x 8 = 40; skips_sum of 16 blocks = 128
 struct HColArgs {
     const char* wstream;            // the slab's packed weights: `nks` k-step images of 4 KiB ([k-half][128 rows][16 B])
     const char* kbase[kColMaxK];    // k-step kk: lane (utterance b, time t, k-half h) reads its B fragment at
@@ -223,6 +223,7 @@ static_assert(sizeof(HCol2Args) <= 4096, "kernel arguments are limited to 4 KiB"
 hipError_t launch_hcol2(int prec, const HCol2Args& a, hipStream_t st);
 hipError_t launch_hcol(int prec, int epi, const HColArgs& a, hipStream_t st);        // dz (HEPI_DGATE), dx (HEPI_STORE; HEPI_LEAKY: masked)
 hipError_t launch_hcol_conv(int prec, bool backward, const HColArgs& a, hipStream_t st);   // 1x1 convs in the series with LeakyReLU epilogues
+hipError_t launch_hcol_skipsum(int prec, const HColArgs& a, hipStream_t st);                // skips_sum of <= 16 equally wide blocks -> leaky series
 static_assert(sizeof(HWgradArgs) <= 4096 && sizeof(HGemmArgs) <= 4096 && sizeof(HFusedArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 hipError_t launch_hgemm(int prec, int MT, int epi, const HGemmArgs& a, hipStream_t st);

@@ -276,7 +276,7 @@ inline void set_hseg(HGemmArgs& a, int i, const HView& v, int off, int nks) {
 
 // profiling classes shared with wn_api.hip (same table, same order)
 enum { KC_PACK = 0, KC_GATE_GEMM, KC_OUT_GEMM, KC_DZ_GEMM, KC_DX_GEMM, KC_WGRAD, KC_WGRAD_REDUCE, KC_CONV_FWD, KC_CONV_BWD_DATA,
-       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX, KC_HCOL_DXDZ };
+       KC_SKIP_GEMM, KC_HLOAD, KC_HGATE, KC_HRES, KC_HDZ, KC_HDX, KC_HSKIP, KC_HWGRAD, KC_EMBED, KC_SYNTH, KC_CTC, KC_HFUSED, KC_HCONV_FWD, KC_HCONV_BWD_DATA, KC_HCOL_DZ, KC_HCOL_DX, KC_HCOL_DXDZ, KC_HCOL_SKIP };
 
 }  // namespace
 
@@ -784,9 +784,21 @@ HPlan plan_hskipsum(const wn_skipsum_shape* s, int prec) {
 }
 }  // namespace
 
+// (+ the 1 KiB line that masked store lanes of the column-owner form write to)
+static size_t hskipsum_bytes(const HPlan& g) { return g.bytes() + 1024; }
+// skips_sum -> leaky series as hcol_kernel (wn_col_skip.hip): one-plane modes, <= 16 blocks of one padded width (64 or 128
+// channels), skip rows of the same padded width
+static bool skipsum_col(const wn_skipsum_shape* s, int precision, const HPlan& g) {
+    if (!col_backward_enabled() || hp_planes(precision) != 1 || g.nslab != 1 || g.MT != 2 || g.k32) return false;
+    const int w = cp32(s->skip_rows);
+    if ((w != 64 && w != 128) || s->nblocks > 16) return false;
+    for (int l = 0; l < s->nblocks; ++l) if (cp32(s->channels[l]) != w) return false;
+    return true;
+}
+
 size_t wn_hskipsum_packed_bytes(const wn_skipsum_shape* s, int precision) {
     if (check_hskipsum(s, precision) != WN_OK) return 0;
-    return plan_hskipsum(s, precision).bytes();
+    return hskipsum_bytes(plan_hskipsum(s, precision));
 }
 
 int wn_hskipsum_pack(const wn_skipsum_shape* s, int precision, const float* const* w_skip, const float* bias_total, void* packed,
@@ -844,6 +856,14 @@ int wn_hskipsum_forward_series(const wn_skipsum_shape* s, int precision, const v
     for (int l = 0; l < s->nblocks; ++l) { set_hseg(a, l, view(z[l], s->channels[l], s->ld, P), 0, g.seg_nks[l]); ksum += s->channels[l]; }
     a.dst[0] = dst_of(view(out_series, s->skip_rows, s->ld, P));
     a.oscale2 = out_scale; a.leaky = leaky_slope; a.flag = overflow_flag;
+    if (skipsum_col(s, precision, g)) {
+        HColArgs c;
+        col_args_common(c, a, s->skip_rows, (char*)packed + g.bytes(), s->batch, s->length, s->ld, s->halo);
+        c.dst = a.dst[0]; c.bias = a.bias; c.oscale2 = out_scale; c.leaky = leaky_slope;
+        wn::ProfScopeShared prof(KC_HCOL_SKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
+        WN_HIP(launch_hcol_skipsum(precision, c, st), "hcol<skipsum series>");
+        return WN_OK;
+    }
     wn::ProfScopeShared prof(KC_HSKIP, 2.0 * s->skip_rows * ksum * (double)s->batch * s->length, st);
     WN_HIP(launch_hgemm(precision, g.kernel(), HEPI_LEAKY, a, st), "hgemm<skipsum series>");
     return WN_OK;
@@ -932,7 +952,7 @@ int wn_hstack_pack_table_build(const wn_block_shape* shapes, const wn_block_para
             plain_tiles(a, g, ss.skip_rows);
             jobs.push_back(a);
             skipsum_offsets[gi] = total;
-            total += align256(g.bytes());
+            total += align256(hskipsum_bytes(g));
         }
     }
     const int nj = (int)jobs.size();
