@@ -23,8 +23,16 @@ EXTRA_FLAGS = {"wn_half.hip": ["-fno-slp-vectorize"], "wn_fused.hip": ["-fno-slp
                "wn_col_conv.hip": ["-fno-slp-vectorize"], "wn_col2.hip": ["-fno-slp-vectorize"], "wn_col_skip.hip": ["-fno-slp-vectorize"]}
 
 
+_ASM = {}
+
+
 def _asm(src, tmp_path):
-    out = str(tmp_path / (src + ".s"))
+    """assembly listing of one kernel file, compiled once per test session (several tests read the same listing)"""
+    if src in _ASM and os.path.exists(_ASM[src]):
+        return _ASM[src]
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="wn_asm_"), src + ".s")
+    _ASM[src] = out
     r = subprocess.run([HIPCC, "-O3", "-std=c++20", "--offload-arch=gfx950", "--cuda-device-only"] + EXTRA_FLAGS.get(src, []) +
                        ["-S", os.path.join(CSRC, src), "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
